@@ -1,0 +1,215 @@
+/*
+ * flowers_hip.h — C ABI of libflowers_hip.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary underneath the v2 nn.Module surface of
+ * ynyeh0221/Oxford-102-Flower-GAN-VAE-latent-diffusion. The
+ * reference has no FFI of its own: every entry point below replaces the ATen
+ * ops that a given reference line executes; the line it replaces is cited as
+ * `v2:N` = /root/reference/v2/model_train_test.py:N.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers (tensor.data_ptr()), sizes as ints; no torch types;
+ *   - the caller owns every buffer incl. the workspace `ws`; the library never
+ *     allocates or frees device memory;
+ *   - all work is enqueued on `stream`; no implicit synchronisation, no
+ *     default-stream use (hipGraph-capturable);
+ *   - return FL_OK (0) or a negative fl_status; fl_last_error_string() has text;
+ *   - activations are fp32, NHWC ("channels-last") in HBM; 3-channel images are
+ *     stored as NHWC with C padded to 4 (pad channel = 0);
+ *   - conv weights are "packed": [Cout][kh][kw][Cin] fp32 (fl_pack_conv_weight).
+ */
+#ifndef FLOWERS_HIP_H
+#define FLOWERS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* fl_stream_t; /* == hipStream_t */
+
+typedef enum fl_status {
+  FL_OK = 0,
+  FL_ERR_BAD_ARG = -1,
+  FL_ERR_WORKSPACE = -2,
+  FL_ERR_LAUNCH = -3,
+  FL_ERR_UNSUPPORTED = -4
+} fl_status;
+
+enum { FL_ACT_NONE = 0, FL_ACT_SWISH = 1, FL_ACT_RELU = 2, FL_ACT_LRELU = 3, FL_ACT_SIGMOID = 4 };
+/* operand layouts for fl_gemm_f32: KC = reduction index contiguous, KS = strided */
+enum { FL_LAYOUT_KC = 0, FL_LAYOUT_KS = 1 };
+
+int fl_version(void);
+const char* fl_last_error_string(void);
+
+
+
+/* ------------------------------------------------------------------------ *
+ * Dense contraction core (fp32-in / fp32-accumulate MFMA, v_mfma_f32_32x32x2_f32)
+ *   C[m][n] = epi( sum_k A(m,k) * B(n,k) )
+ *   A: KC -> A[m*lda + k]   KS -> A[k*lda + m]
+ *   B: KC -> B[n*ldb + k]   KS -> B[k*ldb + n]
+ *   epi(v) : v += bias_scale*bias[n]; if (R && r_pre) v += r_scale*R[m*ldr+n];
+ *            v = act(v); if (R && !r_pre) v += r_scale*R[m*ldr+n]
+ * Replaces nn.Linear forward/backward (v2:211-220, v2:246-252, v2:311-320,
+ * v2:405-431, v2:509-531) and, through the conv entry points, nn.Conv2d /
+ * nn.ConvTranspose2d. K must be a multiple of 4; lda/ldb multiples of 4.
+ * Split-K is used automatically when the tile count is small and `ws` allows.
+ * ------------------------------------------------------------------------ */
+size_t fl_gemm_workspace_bytes(int M, int N, int K);
+int fl_gemm_f32(const float* A, int64_t lda, int a_layout,
+                const float* B, int64_t ldb, int b_layout,
+                float* C, int64_t ldc, int M, int N, int K,
+                const float* bias, float bias_scale,
+                const float* R, int64_t ldr, float r_scale, int r_pre,
+                int act, float act_param,
+                void* ws, size_t ws_bytes, fl_stream_t stream);
+
+/* Implicit-GEMM NHWC convolution, y = act(conv(x, w) + bias) (+ residual R, same
+ * shape as y).  x:(B,H,W,Cin) wp:[Cout][kh][kw][Cin]  y:(B,Ho,Wo,Cout) or, when
+ * out_nchw != 0, (B,Cout,Ho,Wo).  Cin % 4 == 0.
+ * Replaces nn.Conv2d forward: v2:162,165 (3x3 s1 p1), v2:186, v2:192,198,204
+ * (4x4 s2 p1), v2:273,276, VGG16 convs (v2:965), Discriminator64 (v2:987-1002). */
+int fl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y,
+                  int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                  int act, float act_param, const float* R, int out_nchw,
+                  void* ws, size_t ws_bytes, fl_stream_t stream);
+/* dx = conv_transpose(dy, w): input gradient of the conv above (stride 1 any
+ * kernel; stride 2 only for 4x4 p1).  dy:(B,Ho,Wo,Cout) -> dx:(B,H,W,Cin).
+ * wp is the SAME packed weight as the forward. */
+int fl_conv2d_dgrad(const float* dy, const float* wp, float* dx,
+                    int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                    void* ws, size_t ws_bytes, fl_stream_t stream);
+/* dwp[Cout][kh][kw][Cin] = sum_pixels dy (x) x  (packed layout, see fl_unpack_conv_weight) */
+int fl_conv2d_wgrad(const float* dy, const float* x, float* dwp,
+                    int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                    void* ws, size_t ws_bytes, fl_stream_t stream);
+size_t fl_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+/* nn.ConvTranspose2d(k=4,s=2,p=1) forward (v2:256,262,268) as 4 sub-pixel 2x2
+ * convolutions (no zero insertion).  x:(B,H,W,Cin) -> y:(B,2H,2W,Cout).
+ * wtp = fl_pack_conv_weight of the (Cin,Cout,4,4) parameter = [Cin][4][4][Cout]. */
+int fl_convT2d_fwd(const float* x, const float* wtp, const float* bias, float* y,
+                   int B, int H, int W, int Cin, int Cout, int act, float act_param,
+                   void* ws, size_t ws_bytes, fl_stream_t stream);
+
+/* (O,I,kh,kw) -> [O][kh][kw][Ipad] (zero-filled pad channels) and back. */
+int fl_pack_conv_weight(const float* w, float* wp, int O, int I, int kh, int kw, int Ipad, fl_stream_t stream);
+int fl_unpack_conv_weight(const float* wp, float* w, int O, int I, int kh, int kw, int Ipad, fl_stream_t stream);
+
+
+/* ------------------------------------------------------------------------ *
+ * Normalisation family (NHWC, fp32).  `ws` >= fl_norm_workspace_bytes(B,HW,C).
+ * The *_stats entry points run the streaming statistics pass and emit per-(image,
+ * channel) scale/shift such that  norm(x) = x*scale + shift ; fl_affine_act then
+ * applies  y = act(x*scale + shift) (+R)  in one pass.
+ *   fl_instnorm_*  : LayerNorm2d, v2:144-156 (per-(n,c) stats over H*W, biased var)
+ *   fl_groupnorm_* : nn.GroupNorm, v2:257,263,269,274
+ *   fl_batchnorm_* : nn.BatchNorm2d, v2:991,995,999 (training stats + running update)
+ * scale/shift are (B,C) for instance/group norm (per_image=1) and (C) for batch norm.
+ * ------------------------------------------------------------------------ */
+size_t fl_norm_workspace_bytes(int B, int HW, int C);
+int fl_instnorm_stats(const float* x, const float* w, const float* b, float eps, float* scale, float* shift,
+                      float* mean, float* rstd, int B, int HW, int C, void* ws, size_t ws_bytes, fl_stream_t stream);
+int fl_groupnorm_stats(const float* x, const float* w, const float* b, float eps, int G, float* scale, float* shift,
+                       float* mean, float* rstd, int B, int HW, int C, void* ws, size_t ws_bytes, fl_stream_t stream);
+int fl_batchnorm_stats(const float* x, const float* w, const float* b, float eps, float momentum, float* running_mean,
+                       float* running_var, int training, float* scale, float* shift, float* mean, float* rstd, int B,
+                       int HW, int C, void* ws, size_t ws_bytes, fl_stream_t stream);
+int fl_affine_act(const float* x, const float* scale, const float* shift, int per_image, const float* R, float* y, int B,
+                  int HW, int C, int act, float act_param, fl_stream_t stream);
+/* backward of y = act(norm(x)); coef is scratch: 3*B*C floats (3*C for batch norm) */
+int fl_instnorm_bwd(const float* dy, const float* x, const float* scale, const float* shift, const float* w,
+                    const float* mean, const float* rstd, int act, float act_param, float* dx, float* dw, float* db,
+                    float* coef, int B, int HW, int C, void* ws, size_t ws_bytes, fl_stream_t stream);
+int fl_groupnorm_bwd(const float* dy, const float* x, const float* scale, const float* shift, const float* w,
+                     const float* mean, const float* rstd, int G, int act, float act_param, float* dx, float* dw,
+                     float* db, float* coef, int B, int HW, int C, void* ws, size_t ws_bytes, fl_stream_t stream);
+int fl_batchnorm_bwd(const float* dy, const float* x, const float* scale, const float* shift, const float* w,
+                     const float* mean, const float* rstd, int act, float act_param, float* dx, float* dw, float* db,
+                     float* coef, int B, int HW, int C, void* ws, size_t ws_bytes, fl_stream_t stream);
+/* nn.LayerNorm over the last dim (v2:212,218,248,251,313,317,521,525,530):
+ * y = act(mask * (xhat*w + b)); mask (rows,D) optional = dropout scale (v2:522). */
+int fl_layernorm_fwd(const float* x, const float* w, const float* b, const float* mask, float* y, float* mean,
+                     float* rstd, int rows, int D, float eps, int act, float act_param, fl_stream_t stream);
+size_t fl_layernorm_bwd_workspace_bytes(int rows, int D);
+int fl_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mask,
+                     const float* mean, const float* rstd, float* dx, float* dw, float* db, int rows, int D, int act,
+                     float act_param, void* ws, size_t ws_bytes, fl_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Residual-block tail: CALayer (v2:53-67) x SpatialAttention (v2:69-81) x residual+Swish
+ * (v2:176-177) fused into two streaming passes.  u = s[b,c]*(y*scale[b,c]+shift[b,c]).
+ * ------------------------------------------------------------------------ */
+int fl_res_tail_map(const float* y, const float* scale, const float* shift, const float* s, float* map, int B, int HW,
+                    int C, fl_stream_t stream);
+int fl_res_tail_out(const float* y, const float* scale, const float* shift, const float* s, const float* map,
+                    const float* saw, const float* xres, float* out, float* att_out, int B, int H, int W, int C,
+                    int final_swish, fl_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Elementwise / gather / diffusion / RNG
+ * ------------------------------------------------------------------------ */
+int fl_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, int Cpad, fl_stream_t stream);
+int fl_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, int Cpad, fl_stream_t stream);
+int fl_act_fwd(const float* x, float* y, int64_t n, int act, float p, fl_stream_t stream);          /* Swish v2:48-50 */
+int fl_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, float p, fl_stream_t stream);
+int fl_axpby(float a, const float* x, float b, const float* y, float* out, int64_t n, fl_stream_t stream);
+/* attention-dropout of nn.MultiheadAttention on a length-1 sequence (v2:514,550-551) */
+int fl_scale_heads(const float* v, const float* head_mask, float* out, int B, int D, int heads, fl_stream_t stream);
+int fl_add_rows(const float* x, const float* y, int y_rows, float* out, int B, int D, fl_stream_t stream);
+int fl_time_sinusoid(const int64_t* t, float* out, int Bt, int n_ch, fl_stream_t stream);           /* v2:410-414 */
+int fl_embedding_fwd(const float* table, const int64_t* idx, float* out, int n, int D, fl_stream_t stream); /* v2:430 */
+int fl_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, int n, int D, int rows, fl_stream_t stream);
+int fl_q_sample(const float* x0, const float* eps, const int64_t* t, const float* alpha_bar, float* xt, int B, int D,
+                fl_stream_t stream);                                                                  /* v2:574-578 */
+int fl_p_sample_update(const float* xt, const float* eps_theta, const float* noise, const int32_t* t_ptr,
+                       const float* alpha, const float* alpha_bar, const float* beta, float* out, int64_t n,
+                       fl_stream_t stream);                                                           /* v2:584-592 */
+int fl_step_counter_add(int32_t* t_ptr, int64_t* t64_ptr, int delta, fl_stream_t stream);
+int fl_reparameterize(const float* mu, const float* logvar, const float* eps, float* z, float* logvar_clamped,
+                      int64_t n, fl_stream_t stream);                                                 /* v2:339-343,352 */
+/* Philox4x32-10; mode 0 normal, 1 dropout scale {0,1/(1-p)}, 2 uniform. counter = offset + dev_offset[0] */
+int fl_philox_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, const int64_t* dev_offset, int mode, float p,
+                   fl_stream_t stream);
+int fl_philox_randint(int64_t* out, int64_t n, uint64_t seed, uint64_t offset, const int64_t* dev_offset, int hi,
+                      fl_stream_t stream);
+int fl_advance_offset(int64_t* dev_offset, int64_t delta, fl_stream_t stream);
+size_t fl_colsum_workspace_bytes(int M, int N);
+int fl_colsum(const float* x, int64_t ldx, float* out, int M, int N, float beta, void* ws, size_t ws_bytes,
+              fl_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Losses + optimizer tail (device-resident scalars; no host syncs)
+ * ------------------------------------------------------------------------ */
+int fl_euclid_loss_fwd(const float* x, const float* y, float* norms, float* loss, int B, int64_t D, int reduction,
+                       fl_stream_t stream);                                                           /* v2:293-302 */
+int fl_euclid_loss_bwd(const float* x, const float* y, const float* norms, float gscale, const float* gdev, float* dx,
+                       float* dy, int B, int64_t D, int reduction, fl_stream_t stream);
+size_t fl_sqnorm_workspace_bytes(void);
+int fl_sqnorm(const float* x, int64_t n, float* out, int accumulate, void* ws, size_t ws_bytes, fl_stream_t stream);
+int fl_clip_coef(const float* sqnorm, float max_norm, float* coef, float* norm_out, fl_stream_t stream); /* v2:1128,1263 */
+int fl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, const int32_t* step_dev,
+                 float b1, float b2, float eps, float wd, const float* coef_dev, float gscale, int decoupled,
+                 fl_stream_t stream);                                                        /* v2:1026,1028,1247 */
+int fl_kl_fwd(const float* mu, const float* logvar, float* kl_row, float* musq_row, float* loss, int B, int D,
+              fl_stream_t stream);                                                                    /* v2:380-386 */
+int fl_kl_bwd(const float* mu, const float* logvar, const float* kl_row, float gscale, const float* gdev, float* dmu,
+              float* dlv, int B, int D, fl_stream_t stream);
+int fl_bce_fwd(const float* p, float target, float* loss, int n, fl_stream_t stream);                /* v2:1029 */
+int fl_bce_bwd(const float* p, float target, float gscale, const float* gdev, float* dp, int n, fl_stream_t stream);
+int fl_cross_entropy_fwd(const float* logits, const int64_t* labels, float* row_loss, float* probs, float* loss, int B,
+                         int C, fl_stream_t stream);                                                  /* v2:1093 */
+int fl_cross_entropy_bwd(const float* probs, const int64_t* labels, float gscale, const float* gdev, float* dlogits,
+                         int B, int C, fl_stream_t stream);
+int fl_gather_rows(const float* table, const int64_t* idx, float* out, int B, int D, fl_stream_t stream); /* v2:363 */
+int fl_update_centers(float* centers, const float* z, const int64_t* labels, float momentum, int B, int D, int classes,
+                      fl_stream_t stream);                                                            /* v2:369-378 */
+int fl_balance_losses(const float* terms, const float* weights, float* coeff, float* total, fl_stream_t stream); /* v2:1107-1125 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWERS_HIP_H */

@@ -1,0 +1,186 @@
+// Residual-block tail of the VAE (v2:170-178): LayerNorm2d -> CALayer -> SpatialAttention
+// -> (+residual) -> Swish, as two HBM-streaming passes over the conv output instead of the
+// ~20 eager kernels the reference launches:
+//   pass 1 (res_tail_map): u = s[b,c] * (y*scale[b,c] + shift[b,c]); per-pixel channel
+//           mean and max of u -> 2-plane map (B,2,H,W)                 (v2:76-78)
+//   pass 2 (res_tail_out): att = sigmoid(conv7x7(map)) ; out = swish(u*att + x)   (v2:79-81,176-177)
+// NHWC makes the channel reduction a contiguous per-pixel read; a pixel is owned by a
+// group of LPP = min(64, C/4) lanes (float4 per lane) and reduced with wave shuffles.
+#include "fl_common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int LPP>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = LPP / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// u for 4 channels
+__device__ __forceinline__ float4 tail_u(const float* y, const float* scale, const float* shift, const float* s,
+                                         long long pix_off, long long bc_off) {
+  float4 v = ld4(y + pix_off);
+  if (scale) {
+    const float4 sc = ld4(scale + bc_off), sh = ld4(shift + bc_off);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+  }
+  if (s) {
+    const float4 ss = ld4(s + bc_off);
+    v.x *= ss.x; v.y *= ss.y; v.z *= ss.z; v.w *= ss.w;
+  }
+  return v;
+}
+
+template <int LPP>
+__global__ void res_tail_map_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const float* __restrict__ s,
+                                    float* __restrict__ map, int B, int HW, int C) {
+  constexpr int PPW = 64 / LPP;  // pixels per wave
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int gl = lane % LPP, gp = lane / LPP;
+  const long long npix = (long long)B * HW;
+  const int C4 = C >> 2;
+  const long long wave0 = ((long long)blockIdx.x * (blockDim.x >> 6) + wid) * PPW;
+  const long long wstride = (long long)gridDim.x * (blockDim.x >> 6) * PPW;
+  for (long long pw = wave0; pw < npix; pw += wstride) {
+    const long long pix = pw + gp;
+    const bool ok = pix < npix;
+    const long long pp = ok ? pix : 0;
+    const int b = (int)(pp / HW);
+    float sum = 0.f, mx = -INFINITY;
+    for (int c4 = gl; c4 < C4; c4 += LPP) {
+      const float4 u = tail_u(y, scale, shift, s, pp * C + c4 * 4, (long long)b * C + c4 * 4);
+      sum += (u.x + u.y) + (u.z + u.w);
+      mx = fmaxf(fmaxf(mx, fmaxf(u.x, u.y)), fmaxf(u.z, u.w));
+    }
+    sum = group_sum<LPP>(sum);
+    mx = group_max<LPP>(mx);
+    if (ok && gl == 0) {
+      const int p = (int)(pp - (long long)b * HW);
+      map[((long long)b * 2) * HW + p] = sum / C;
+      map[((long long)b * 2 + 1) * HW + p] = mx;
+    }
+  }
+}
+
+template <int LPP>
+__global__ void res_tail_out_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const float* __restrict__ s,
+                                    const float* __restrict__ map, const float* __restrict__ saw,
+                                    const float* __restrict__ xres, float* __restrict__ out, float* __restrict__ att_out,
+                                    int B, int H, int W, int C, int final_swish) {
+  constexpr int PPW = 64 / LPP;
+  __shared__ float wsm[98];
+  if (map) {
+    for (int i = threadIdx.x; i < 98; i += blockDim.x) wsm[i] = saw[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int gl = lane % LPP, gp = lane / LPP;
+  const int HW = H * W;
+  const long long npix = (long long)B * HW;
+  const int C4 = C >> 2;
+  const long long wave0 = ((long long)blockIdx.x * (blockDim.x >> 6) + wid) * PPW;
+  const long long wstride = (long long)gridDim.x * (blockDim.x >> 6) * PPW;
+  for (long long pw = wave0; pw < npix; pw += wstride) {
+    const long long pix = pw + gp;
+    const bool ok = pix < npix;
+    const long long pp = ok ? pix : 0;
+    const int b = (int)(pp / HW);
+    const int p = (int)(pp - (long long)b * HW);
+    float att = 1.f;
+    if (map) {
+      const int py = p / W, px = p - py * W;
+      float a = 0.f;
+      for (int t = gl; t < 98; t += LPP) {
+        const int ch = t / 49, r = t - ch * 49;
+        const int dy = r / 7 - 3, dx = r % 7 - 3;
+        const int yy = py + dy, xx = px + dx;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+          a += wsm[t] * map[((long long)b * 2 + ch) * HW + yy * W + xx];
+      }
+      a = group_sum<LPP>(a);
+      att = fl::sigmoid_acc(a);
+      if (att_out && ok && gl == 0) att_out[pp] = att;
+    }
+    if (!ok) continue;
+    for (int c4 = gl; c4 < C4; c4 += LPP) {
+      const long long off = pp * C + c4 * 4;
+      float4 u = tail_u(y, scale, shift, s, off, (long long)b * C + c4 * 4);
+      u.x *= att; u.y *= att; u.z *= att; u.w *= att;
+      if (xres) {
+        const float4 r = ld4(xres + off);
+        u.x += r.x; u.y += r.y; u.z += r.z; u.w += r.w;
+      }
+      if (final_swish) {
+        u.x = fl::swish_acc(u.x); u.y = fl::swish_acc(u.y); u.z = fl::swish_acc(u.z); u.w = fl::swish_acc(u.w);
+      }
+      st4(out + off, u);
+    }
+  }
+}
+
+static int tail_blocks(long long npix, int ppw) {
+  long long waves = (npix + ppw - 1) / ppw;
+  long long blocks = (waves + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+// map (B,2,H*W): plane 0 = channel mean, plane 1 = channel max of u = s*(y*scale+shift)
+// (scale/shift/s may be NULL = identity).  Replaces v2:76-78 (+ v2:151-155, v2:67 fused in).
+int fl_res_tail_map(const float* y, const float* scale, const float* shift, const float* s, float* map, int B, int HW,
+                    int C, fl_stream_t stream) {
+  FL_REQUIRE(y && map && C % 4 == 0, "fl_res_tail_map: bad args");
+  FL_REQUIRE((scale == nullptr) == (shift == nullptr), "fl_res_tail_map: scale/shift must come together");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long npix = (long long)B * HW;
+  if (npix == 0) return FL_OK;
+  const int C4 = C / 4;
+#define LAUNCH_MAP(L) hipLaunchKernelGGL(res_tail_map_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, B, HW, C)
+  if (C4 >= 64) LAUNCH_MAP(64);
+  else if (C4 >= 32) LAUNCH_MAP(32);
+  else if (C4 >= 16) LAUNCH_MAP(16);
+  else if (C4 >= 8) LAUNCH_MAP(8);
+  else LAUNCH_MAP(1);
+#undef LAUNCH_MAP
+  return fl::check_launch("res_tail_map_kernel");
+}
+
+// out = [swish]( u * sigmoid(conv7x7(map, saw)) + xres ), u as above. map NULL -> att = 1.
+// att_out (B,H*W) optional (saved for backward). Replaces v2:79-81 and v2:176-177.
+int fl_res_tail_out(const float* y, const float* scale, const float* shift, const float* s, const float* map,
+                    const float* saw, const float* xres, float* out, float* att_out, int B, int H, int W, int C,
+                    int final_swish, fl_stream_t stream) {
+  FL_REQUIRE(y && out && C % 4 == 0, "fl_res_tail_out: bad args");
+  FL_REQUIRE((map == nullptr) || (saw != nullptr), "fl_res_tail_out: map needs conv weights");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long npix = (long long)B * H * W;
+  if (npix == 0) return FL_OK;
+  const int C4 = C / 4;
+#define LAUNCH_OUT(L) hipLaunchKernelGGL(res_tail_out_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, saw, xres, out, att_out, B, H, W, C, final_swish)
+  if (C4 >= 64) LAUNCH_OUT(64);
+  else if (C4 >= 32) LAUNCH_OUT(32);
+  else if (C4 >= 16) LAUNCH_OUT(16);
+  else if (C4 >= 8) LAUNCH_OUT(8);
+  else LAUNCH_OUT(1);
+#undef LAUNCH_OUT
+  return fl::check_launch("res_tail_out_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// Common device/host helpers for the flowers_hip library (gfx950 / CDNA4 only).
+// Wavefront = 64 lanes everywhere in this code base.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/flowers_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+namespace fl {
+
+// ---- error plumbing (never throws across the C ABI) -------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);  // hipGetLastError -> status
+
+#define FL_REQUIRE(cond, ...)                 \
+  do {                                        \
+    if (!(cond)) {                            \
+      fl::set_error(__VA_ARGS__);             \
+      return FL_ERR_BAD_ARG;                  \
+    }                                         \
+  } while (0)
+
+// ---- activations -------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// accurate sigmoid (expf, not the fast intrinsic) – used where parity matters
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float swish_acc(float x) { return x * sigmoid_acc(x); }
+// d/dx [x*sigmoid(x)] = s*(1 + x*(1-s))
+__device__ __forceinline__ float swish_grad(float x) {
+  float s = sigmoid_acc(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float p) {
+  switch (act) {
+    case FL_ACT_SWISH: return swish_acc(v);
+    case FL_ACT_RELU: return v > 0.f ? v : 0.f;
+    case FL_ACT_LRELU: return v > 0.f ? v : v * p;
+    case FL_ACT_SIGMOID: return sigmoid_acc(v);
+    default: return v;
+  }
+}
+
+// ---- wave / block reductions (64-lane waves) ------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum; `red` is >= (blockDim.x/64) floats of LDS. Result valid in all threads.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+  return r;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace fl

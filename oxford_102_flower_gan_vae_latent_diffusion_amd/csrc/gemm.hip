@@ -1,0 +1,643 @@
+// Dense-contraction core for gfx950: one templated LDS-tiled kernel on the
+// fp32-in/fp32-accumulate MFMA (v_mfma_f32_32x32x2_f32, exact fp32, 64 FLOP/clk/SIMD).
+//
+// Every GEMM-shaped op of the v2 module surface goes through this file:
+//   nn.Linear fwd / dgrad / wgrad, nn.Conv2d fwd / dgrad / wgrad as implicit GEMM over
+//   NHWC activations (im2col is never materialised: the A (or B) tile loader gathers
+//   taps straight from HBM into LDS), nn.ConvTranspose2d(4,2,1) as 4 sub-pixel classes.
+//
+// Tiling: block = 256 threads = 4 waves (64 lanes each); block tile BM x BN x 32;
+// each wave owns a (BM/WGM) x (BN/WGN) sub-tile made of 32x32 MFMA tiles whose
+// accumulators live in VGPR/AGPRs. Global -> registers -> LDS staging, double-buffered
+// in LDS, one barrier per K-chunk; the next chunk's global loads are issued before the
+// current chunk's MFMAs so HBM/L2 latency hides under the (long) fp32 MFMA phase.
+//
+// LDS images (conflict-free by construction, see MI355X_MICROARCH §LDS):
+//   KC operand (reduction index contiguous in memory):  tile[rows][36]  (32 + 4 pad)
+//       written with ds_write_b128, read with ds_read_b128: slot = 9*row + k/4 (mod 16)
+//       is a permutation over any 16 consecutive rows.
+//   KS operand (reduction index strided in memory):     tile[32][rows]
+//       written with ds_write_b128 along rows, read with ds_read_b32 (32 consecutive
+//       rows per half-wave -> conflict-free).
+// The k-slot assignment is the same for both images: lane half h, step q, element j
+// uses k = 4*(2q+h)+j of the 32-chunk, so A and B fragments always pair the same k.
+#include "fl_common.h"
+#include <cstring>
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = 36;
+
+enum { A_KC_PLAIN = 0, A_KC_CONV = 1, A_KC_TCONV = 2, A_KS_PLAIN = 3 };
+enum { B_KC_PLAIN = 0, B_KS_PLAIN = 1, B_KS_TAPFLIP = 2, B_KS_TAPCLS = 3, B_KS_IM2COL = 4 };
+enum { OUT_ROWMAJOR = 0, OUT_NCHW = 1, OUT_TCONV = 2 };
+
+struct GArgs {
+  int M, N, K;
+  // A operand
+  const float* A;
+  long long lda;
+  int a_vec;  // 16-B vector loads legal
+  // gather geometry shared by A_KC_CONV / A_KC_TCONV / B_KS_IM2COL
+  int H, W, Cin;   // spatial dims + channels of the tensor being gathered from
+  int Ho, Wo;      // dims the GEMM row (or reduction) index is decoded over
+  int kw, stride, pad;
+  // B operand
+  const float* B;
+  long long ldb;
+  int b_vec;
+  int b_taps, b_Cred, b_Cn;  // tapped weights (dgrad / transposed conv)
+  // epilogue
+  float* C;
+  long long ldc;
+  int out_mode;
+  const float* bias;
+  float bias_scale;
+  const float* R;
+  long long ldr;
+  float r_scale;
+  int r_pre;
+  int act;
+  float act_param;
+  // tiling
+  int tiles_n;
+  int splitk, chunks_per_split;
+  float* ws;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// guarded load of up to 4 consecutive floats (nvalid in 0..4), vector when legal
+__device__ __forceinline__ float4 ld4g(const float* p, int nvalid, int vec) {
+  if (nvalid >= 4 && vec) return ld4(p);
+  float4 v = zero4();
+  if (nvalid > 0) v.x = p[0];
+  if (nvalid > 1) v.y = p[1];
+  if (nvalid > 2) v.z = p[2];
+  if (nvalid > 3) v.w = p[3];
+  return v;
+}
+
+__device__ __forceinline__ float epilogue_value(const GArgs& g, float v, int col, const float* rptr) {
+  if (g.bias) v += g.bias_scale * g.bias[col];
+  if (rptr && g.r_pre) v += g.r_scale * (*rptr);
+  v = fl::apply_act(v, g.act, g.act_param);
+  if (rptr && !g.r_pre) v += g.r_scale * (*rptr);
+  return v;
+}
+
+template <int BM, int BN, int WGM, int WGN, int AM, int BMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
+  static_assert(WGM * WGN == 4, "4 waves per block");
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int ANR = BM / 32, BNR = BN / 32;  // float4 per thread per chunk
+  constexpr bool A_KS = (AM == A_KS_PLAIN);
+  constexpr bool B_KS = (BMODE != B_KC_PLAIN);
+  constexpr int A_TILE = BM * LDK, B_TILE = BN * LDK;  // floats per buffer (KS image is smaller)
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid / WGN, wc = wid % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int tile = blockIdx.x;
+  const int tile_m0 = (tile / g.tiles_n) * BM;
+  const int tile_n0 = (tile % g.tiles_n) * BN;
+  const int cls = blockIdx.y;  // sub-pixel class (transposed conv only)
+  const int py = cls >> 1, px = cls & 1;
+  const int z = blockIdx.z;
+
+  int kc_begin = 0, kc_end = (g.K + BK - 1) / BK;
+  if (g.splitk > 1) {
+    kc_begin = z * g.chunks_per_split;
+    int e = kc_begin + g.chunks_per_split;
+    kc_end = e < kc_end ? e : kc_end;
+  }
+
+  // ------------------------------------------------------------------ A loader state
+  // KC mapping: thread -> (row = tid>>3 (+32r), 4 consecutive k at (tid&7)*4)
+  const int ld_row = tid >> 3, kq = (tid & 7) * 4;
+  // KS mapping for an operand of R rows: TPR = R/4 threads per k-row
+  constexpr int A_TPR = BM / 4, A_RPP = 256 / A_TPR;
+  constexpr int B_TPR = BN / 4, B_RPP = 256 / B_TPR;
+  const int a_ks_row = tid / A_TPR, a_ks_c = (tid % A_TPR) * 4;
+  const int b_ks_row = tid / B_TPR, b_ks_c = (tid % B_TPR) * 4;
+
+  long long a_base[ANR];
+  int a_iy0[ANR], a_ix0[ANR];
+  bool a_ok[ANR];
+  if constexpr (!A_KS) {
+#pragma unroll
+    for (int r = 0; r < ANR; ++r) {
+      const int m = tile_m0 + ld_row + 32 * r;
+      a_ok[r] = m < g.M;
+      a_iy0[r] = 0;
+      a_ix0[r] = 0;
+      if constexpr (AM == A_KC_PLAIN) {
+        a_base[r] = (long long)m * g.lda;
+      } else {
+        const int hw = g.Ho * g.Wo;
+        const int mm = a_ok[r] ? m : 0;
+        const int img = mm / hw, p = mm - img * hw;
+        const int oy = p / g.Wo, ox = p - oy * g.Wo;
+        if constexpr (AM == A_KC_CONV) {
+          a_iy0[r] = oy * g.stride - g.pad;
+          a_ix0[r] = ox * g.stride - g.pad;
+        } else {  // A_KC_TCONV: rows are (img, yh, xh) of the low-res tensor
+          a_iy0[r] = oy + py;
+          a_ix0[r] = ox + px;
+        }
+        a_base[r] = (((long long)img * g.H + a_iy0[r]) * g.W + a_ix0[r]) * g.Cin;
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ B loader state
+  long long b_base[BNR];
+  bool b_ok[BNR];
+  int b_ky = 0, b_kx = 0, b_ci = 0;  // im2col column decode (fixed per thread)
+  if constexpr (BMODE == B_KC_PLAIN) {
+#pragma unroll
+    for (int r = 0; r < BNR; ++r) {
+      const int n = tile_n0 + ld_row + 32 * r;
+      b_ok[r] = n < g.N;
+      b_base[r] = (long long)n * g.ldb;
+    }
+  } else if constexpr (BMODE == B_KS_IM2COL) {
+    const int n = tile_n0 + b_ks_c;
+    const int tap = n / g.Cin;
+    b_ci = n - tap * g.Cin;
+    b_ky = tap / g.kw;
+    b_kx = tap - b_ky * g.kw;
+  }
+
+  auto load_A = [&](int kc, float4 (&regs)[ANR]) {
+    if constexpr (!A_KS) {
+      const int k = kc * BK + kq;
+      const int kleft = g.K - k;
+      long long off = k;
+      int dy = 0, dx = 0;
+      if constexpr (AM == A_KC_CONV) {
+        const int tap = k / g.Cin, c = k - tap * g.Cin;
+        dy = tap / g.kw;
+        dx = tap - dy * g.kw;
+        off = ((long long)dy * g.W + dx) * g.Cin + c;
+      } else if constexpr (AM == A_KC_TCONV) {
+        const int tap = k / g.Cin, c = k - tap * g.Cin;
+        dy = -(tap >> 1);
+        dx = -(tap & 1);
+        off = ((long long)dy * g.W + dx) * g.Cin + c;
+      }
+#pragma unroll
+      for (int r = 0; r < ANR; ++r) {
+        bool ok = a_ok[r] && kleft > 0;
+        if constexpr (AM != A_KC_PLAIN) {
+          ok = ok && (unsigned)(a_iy0[r] + dy) < (unsigned)g.H && (unsigned)(a_ix0[r] + dx) < (unsigned)g.W;
+        }
+        regs[r] = ok ? ld4g(g.A + a_base[r] + off, kleft, g.a_vec) : zero4();
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < ANR; ++p) {
+        const int kk = kc * BK + a_ks_row + p * A_RPP;
+        const int m = tile_m0 + a_ks_c;
+        const bool ok = kk < g.K && m < g.M;
+        regs[p] = ok ? ld4g(g.A + (long long)kk * g.lda + m, g.M - m, g.a_vec) : zero4();
+      }
+    }
+  };
+
+  auto load_B = [&](int kc, float4 (&regs)[BNR]) {
+    if constexpr (BMODE == B_KC_PLAIN) {
+      const int k = kc * BK + kq;
+      const int kleft = g.K - k;
+#pragma unroll
+      for (int r = 0; r < BNR; ++r) {
+        const bool ok = b_ok[r] && kleft > 0;
+        regs[r] = ok ? ld4g(g.B + b_base[r] + k, kleft, g.b_vec) : zero4();
+      }
+    } else {
+      const int n = tile_n0 + b_ks_c;
+#pragma unroll
+      for (int p = 0; p < BNR; ++p) {
+        const int kk = kc * BK + b_ks_row + p * B_RPP;
+        bool ok = kk < g.K && n < g.N;
+        const float* src = g.B;
+        if constexpr (BMODE == B_KS_PLAIN) {
+          src += (long long)kk * g.ldb + n;
+        } else if constexpr (BMODE == B_KS_TAPFLIP || BMODE == B_KS_TAPCLS) {
+          const int kks = ok ? kk : 0;
+          const int tapi = kks / g.b_Cred, cr = kks - tapi * g.b_Cred;
+          int tap;
+          if constexpr (BMODE == B_KS_TAPFLIP) {
+            tap = g.b_taps - 1 - tapi;
+          } else {
+            const int ky = (1 - py) + 2 * (tapi >> 1), kx = (1 - px) + 2 * (tapi & 1);
+            tap = ky * 4 + kx;
+          }
+          src += ((long long)cr * g.b_taps + tap) * g.b_Cn + n;
+        } else {  // B_KS_IM2COL: reduction index = output pixel, column = (tap, ci)
+          const int kks = ok ? kk : 0;
+          const int hw = g.Ho * g.Wo;
+          const int img = kks / hw, pp = kks - img * hw;
+          const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
+          const int iy = oy * g.stride - g.pad + b_ky, ix = ox * g.stride - g.pad + b_kx;
+          ok = ok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+          src += (((long long)img * g.H + iy) * g.W + ix) * g.Cin + b_ci;
+        }
+        regs[p] = ok ? ld4g(src, g.N - n, g.b_vec) : zero4();
+      }
+    }
+  };
+
+  auto store_A = [&](int buf, const float4 (&regs)[ANR]) {
+    float* S = As + buf * A_TILE;
+#pragma unroll
+    for (int r = 0; r < ANR; ++r) {
+      if constexpr (!A_KS)
+        *reinterpret_cast<float4*>(S + (ld_row + 32 * r) * LDK + kq) = regs[r];
+      else
+        *reinterpret_cast<float4*>(S + (a_ks_row + r * A_RPP) * BM + a_ks_c) = regs[r];
+    }
+  };
+  auto store_B = [&](int buf, const float4 (&regs)[BNR]) {
+    float* S = Bs + buf * B_TILE;
+#pragma unroll
+    for (int r = 0; r < BNR; ++r) {
+      if constexpr (!B_KS)
+        *reinterpret_cast<float4*>(S + (ld_row + 32 * r) * LDK + kq) = regs[r];
+      else
+        *reinterpret_cast<float4*>(S + (b_ks_row + r * B_RPP) * BN + b_ks_c) = regs[r];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[ANR], rb[BNR];
+  if (kc_begin < kc_end) {
+    load_A(kc_begin, ra);
+    load_B(kc_begin, rb);
+    store_A(0, ra);
+    store_B(0, rb);
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
+    const bool more = kc + 1 < kc_end;
+    if (more) {
+      load_A(kc + 1, ra);
+      load_B(kc + 1, rb);
+    }
+    const float* Sa = As + buf * A_TILE;
+    const float* Sb = Bs + buf * B_TILE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k4 = 4 * (2 * q + lh);
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row = wr * WM + tm * 32 + li;
+        if constexpr (!A_KS) {
+          af[tm] = *reinterpret_cast<const float4*>(Sa + row * LDK + k4);
+        } else {
+          af[tm].x = Sa[(k4 + 0) * BM + row];
+          af[tm].y = Sa[(k4 + 1) * BM + row];
+          af[tm].z = Sa[(k4 + 2) * BM + row];
+          af[tm].w = Sa[(k4 + 3) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int row = wc * WN + tn * 32 + li;
+        if constexpr (!B_KS) {
+          bf[tn] = *reinterpret_cast<const float4*>(Sb + row * LDK + k4);
+        } else {
+          bf[tn].x = Sb[(k4 + 0) * BN + row];
+          bf[tn].y = Sb[(k4 + 1) * BN + row];
+          bf[tn].z = Sb[(k4 + 2) * BN + row];
+          bf[tn].w = Sb[(k4 + 3) * BN + row];
+        }
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].x, bf[tn].x, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].y, bf[tn].y, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].z, bf[tn].z, acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].w, bf[tn].w, acc[tm][tn], 0, 0, 0);
+        }
+    }
+    if (more) {
+      store_A(buf ^ 1, ra);
+      store_B(buf ^ 1, rb);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = tile_m0 + wr * WM + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (m >= g.M) continue;
+      if (g.splitk > 1) {
+        float* wrow = g.ws + ((long long)z * g.M + m) * g.N;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int col = tile_n0 + wc * WN + tn * 32 + li;
+          if (col < g.N) wrow[col] = acc[tm][tn][e];
+        }
+        continue;
+      }
+      long long row_off, col_stride = 1, rrow_off;
+      if (g.out_mode == OUT_ROWMAJOR) {
+        row_off = (long long)m * g.ldc;
+        rrow_off = (long long)m * g.ldr;
+      } else if (g.out_mode == OUT_NCHW) {
+        const int hw = g.Ho * g.Wo;
+        const int img = m / hw, p = m - img * hw;
+        row_off = (long long)img * g.N * hw + p;
+        col_stride = hw;
+        rrow_off = row_off;
+      } else {  // OUT_TCONV: row (img,yh,xh) of class (py,px) -> pixel (2yh+py, 2xh+px)
+        const int hw = g.Ho * g.Wo;
+        const int img = m / hw, p = m - img * hw;
+        const int yh = p / g.Wo, xh = p - yh * g.Wo;
+        row_off = (((long long)img * (2 * g.Ho) + (2 * yh + py)) * (2 * g.Wo) + (2 * xh + px)) * g.ldc;
+        rrow_off = row_off;
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = tile_n0 + wc * WN + tn * 32 + li;
+        if (col >= g.N) continue;
+        const float* rptr = g.R ? g.R + rrow_off + (long long)col * col_stride : nullptr;
+        g.C[row_off + (long long)col * col_stride] = epilogue_value(g, acc[tm][tn][e], col, rptr);
+      }
+    }
+  }
+}
+
+// split-K combine + epilogue (row-major outputs only)
+__global__ void splitk_reduce_kernel(const GArgs g) {
+  const long long total = (long long)g.M * g.N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / g.N), col = (int)(i - (long long)m * g.N);
+    float v = 0.f;
+    for (int zz = 0; zz < g.splitk; ++zz) v += g.ws[(long long)zz * total + i];
+    const float* rptr = g.R ? g.R + (long long)m * g.ldr + col : nullptr;
+    g.C[(long long)m * g.ldc + col] = epilogue_value(g, v, col, rptr);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int AM, int BMODE>
+int launch_cfg(GArgs g, int classes, hipStream_t stream) {
+  constexpr size_t lds = 2u * (BM + BN) * LDK * sizeof(float);
+  static bool attr_set = false;
+  auto kern = gemm_kernel<BM, BN, WGM, WGN, AM, BMODE>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int tiles_m = fl::cdiv(g.M, BM);
+  g.tiles_n = fl::cdiv(g.N, BN);
+  dim3 grid((unsigned)(tiles_m * g.tiles_n), (unsigned)classes, (unsigned)(g.splitk > 1 ? g.splitk : 1));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
+  return fl::check_launch("gemm_kernel");
+}
+
+// tile-shape + split-K policy. `classes` = 4 for transposed conv, else 1.
+template <int AM, int BMODE>
+int launch_gemm(GArgs g, int classes, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (g.M <= 0 || g.N <= 0) return FL_OK;
+  const int nk = fl::cdiv(g.K, BK);
+  // pick tile
+  int bm = 128, bn = 128;
+  if (g.N <= 32) bn = 32;
+  else if (g.N <= 64 || (g.N % 128 != 0 && g.N % 128 <= 64 && g.N < 512)) bn = 64;
+  long long tiles = (long long)fl::cdiv(g.M, bm) * fl::cdiv(g.N, bn) * classes;
+  if (bn == 128 && tiles < 192) {  // small problem: smaller tiles fill more CUs
+    bm = 64;
+    bn = 64;
+    tiles = (long long)fl::cdiv(g.M, bm) * fl::cdiv(g.N, bn) * classes;
+  }
+  // split-K when the grid still cannot fill 256 CUs (row-major epilogue only)
+  g.splitk = 1;
+  g.chunks_per_split = nk;
+  g.ws = reinterpret_cast<float*>(ws);
+  if (g.out_mode == OUT_ROWMAJOR && classes == 1 && tiles < 160 && nk >= 8 && ws != nullptr) {
+    int want = (int)((320 + tiles - 1) / tiles);
+    int maxs = nk / 4;
+    if (want > maxs) want = maxs;
+    const size_t per = (size_t)g.M * g.N * sizeof(float);
+    if (per > 0 && (size_t)want * per > ws_bytes) want = (int)(ws_bytes / per);
+    if (want >= 2) {
+      g.chunks_per_split = fl::cdiv(nk, want);
+      g.splitk = fl::cdiv(nk, g.chunks_per_split);
+    }
+  }
+  int st;
+  if (bm == 128 && bn == 128) st = launch_cfg<128, 128, 2, 2, AM, BMODE>(g, classes, stream);
+  else if (bm == 128 && bn == 64) st = launch_cfg<128, 64, 2, 2, AM, BMODE>(g, classes, stream);
+  else if (bm == 128 && bn == 32) st = launch_cfg<128, 32, 4, 1, AM, BMODE>(g, classes, stream);
+  else st = launch_cfg<64, 64, 2, 2, AM, BMODE>(g, classes, stream);
+  if (st != FL_OK) return st;
+  if (g.splitk > 1) {
+    const long long total = (long long)g.M * g.N;
+    int blocks = fl::cdiv(total, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g);
+    return fl::check_launch("splitk_reduce_kernel");
+  }
+  return FL_OK;
+}
+
+inline int is_vec(const void* p, long long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
+
+GArgs base_args() {
+  GArgs g;
+  memset(&g, 0, sizeof(g));
+  g.bias_scale = 1.f;
+  g.r_scale = 1.f;
+  g.kw = 1;
+  g.stride = 1;
+  g.Cin = 1;
+  g.Ho = g.Wo = 1;
+  g.b_Cred = 1;
+  return g;
+}
+
+// (O, I, kh, kw) <-> [O][kh][kw][Ipad]
+__global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int O, int I, int taps, int Ipad) {
+  const long long total = (long long)O * taps * Ipad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ipad);
+    const long long r = i / Ipad;
+    const int tap = (int)(r % taps);
+    const int o = (int)(r / taps);
+    wp[i] = ci < I ? w[((long long)o * I + ci) * taps + tap] : 0.f;
+  }
+}
+__global__ void unpack_w_kernel(const float* __restrict__ wp, float* __restrict__ w, int O, int I, int taps, int Ipad) {
+  const long long total = (long long)O * I * taps;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const long long r = i / taps;
+    const int ci = (int)(r % I);
+    const int o = (int)(r / I);
+    w[i] = wp[((long long)o * taps + tap) * Ipad + ci];
+  }
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+size_t fl_gemm_workspace_bytes(int M, int N, int K) {
+  const int nk = fl::cdiv(K, BK);
+  int maxs = nk / 4;
+  if (maxs < 1) maxs = 1;
+  if (maxs > 80) maxs = 80;
+  return (size_t)maxs * (size_t)M * (size_t)N * sizeof(float);
+}
+
+int fl_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, int64_t ldb, int b_layout,
+                float* C, int64_t ldc, int M, int N, int K, const float* bias, float bias_scale,
+                const float* R, int64_t ldr, float r_scale, int r_pre, int act, float act_param,
+                void* ws, size_t ws_bytes, fl_stream_t stream) {
+  FL_REQUIRE(A && B && C, "fl_gemm_f32: null operand");
+  FL_REQUIRE(M >= 0 && N >= 0 && K > 0, "fl_gemm_f32: bad dims M=%d N=%d K=%d", M, N, K);
+  GArgs g = base_args();
+  g.M = M; g.N = N; g.K = K;
+  g.A = A; g.lda = lda; g.a_vec = is_vec(A, lda);
+  g.B = B; g.ldb = ldb; g.b_vec = is_vec(B, ldb);
+  g.C = C; g.ldc = ldc; g.out_mode = OUT_ROWMAJOR;
+  g.bias = bias; g.bias_scale = bias_scale;
+  g.R = R; g.ldr = ldr; g.r_scale = r_scale; g.r_pre = r_pre;
+  g.act = act; g.act_param = act_param;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (a_layout == FL_LAYOUT_KC && b_layout == FL_LAYOUT_KC) return launch_gemm<A_KC_PLAIN, B_KC_PLAIN>(g, 1, ws, ws_bytes, s);
+  if (a_layout == FL_LAYOUT_KC && b_layout == FL_LAYOUT_KS) return launch_gemm<A_KC_PLAIN, B_KS_PLAIN>(g, 1, ws, ws_bytes, s);
+  if (a_layout == FL_LAYOUT_KS && b_layout == FL_LAYOUT_KS) return launch_gemm<A_KS_PLAIN, B_KS_PLAIN>(g, 1, ws, ws_bytes, s);
+  fl::set_error("fl_gemm_f32: unsupported layout combination a=%d b=%d", a_layout, b_layout);
+  return FL_ERR_UNSUPPORTED;
+}
+
+int fl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, int B, int H, int W, int Cin,
+                  int Cout, int kh, int kw, int stride, int pad, int act, float act_param, const float* R,
+                  int out_nchw, void* ws, size_t ws_bytes, fl_stream_t stream) {
+  FL_REQUIRE(x && wp && y, "fl_conv2d_fwd: null operand");
+  FL_REQUIRE(Cin % 4 == 0, "fl_conv2d_fwd: Cin=%d must be a multiple of 4 (pad RGB to 4)", Cin);
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  FL_REQUIRE(Ho > 0 && Wo > 0, "fl_conv2d_fwd: empty output");
+  GArgs g = base_args();
+  g.M = B * Ho * Wo; g.N = Cout; g.K = kh * kw * Cin;
+  g.A = x; g.a_vec = is_vec(x, Cin);
+  g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.kw = kw; g.stride = stride; g.pad = pad;
+  g.B = wp; g.ldb = g.K; g.b_vec = is_vec(wp, g.K);
+  g.C = y; g.ldc = Cout; g.out_mode = out_nchw ? OUT_NCHW : OUT_ROWMAJOR;
+  g.bias = bias; g.R = R; g.ldr = Cout; g.act = act; g.act_param = act_param;
+  FL_REQUIRE(!(out_nchw && R), "fl_conv2d_fwd: residual with NCHW output unsupported");
+  return launch_gemm<A_KC_CONV, B_KC_PLAIN>(g, 1, ws, ws_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+int fl_conv2d_dgrad(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cin, int Cout, int kh,
+                    int kw, int stride, int pad, void* ws, size_t ws_bytes, fl_stream_t stream) {
+  FL_REQUIRE(dy && wp && dx, "fl_conv2d_dgrad: null operand");
+  FL_REQUIRE(Cout % 4 == 0 && Cin % 4 == 0, "fl_conv2d_dgrad: channels must be multiples of 4");
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  GArgs g = base_args();
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stride == 1) {
+    // dx[n,iy,ix,ci] = sum_{tap',co} dy[n, iy-(kh-1-pad)+ky', ix-(kw-1-pad)+kx', co] * w[co][flip(tap')][ci]
+    FL_REQUIRE(kh - 1 - pad >= 0 && kw - 1 - pad >= 0, "fl_conv2d_dgrad: pad > k-1 unsupported");
+    FL_REQUIRE(kh - 1 - pad == kw - 1 - pad, "fl_conv2d_dgrad: square padding only");
+    g.M = B * H * W; g.N = Cin; g.K = kh * kw * Cout;
+    g.A = dy; g.a_vec = is_vec(dy, Cout);
+    g.H = Ho; g.W = Wo; g.Cin = Cout; g.Ho = H; g.Wo = W; g.kw = kw; g.stride = 1; g.pad = kh - 1 - pad;
+    g.B = wp; g.b_vec = is_vec(wp, Cin); g.b_taps = kh * kw; g.b_Cred = Cout; g.b_Cn = Cin;
+    g.C = dx; g.ldc = Cin; g.out_mode = OUT_ROWMAJOR;
+    return launch_gemm<A_KC_CONV, B_KS_TAPFLIP>(g, 1, ws, ws_bytes, s);
+  }
+  FL_REQUIRE(stride == 2 && kh == 4 && kw == 4 && pad == 1 && H == 2 * Ho && W == 2 * Wo,
+             "fl_conv2d_dgrad: stride-2 path needs 4x4 p1 and even input dims");
+  // 4 sub-pixel classes; rows per class = (img, yh, xh) over the low-res (Ho, Wo) grid
+  g.M = B * Ho * Wo; g.N = Cin; g.K = 4 * Cout;
+  g.A = dy; g.a_vec = is_vec(dy, Cout);
+  g.H = Ho; g.W = Wo; g.Cin = Cout; g.Ho = Ho; g.Wo = Wo;
+  g.B = wp; g.b_vec = is_vec(wp, Cin); g.b_taps = 16; g.b_Cred = Cout; g.b_Cn = Cin;
+  g.C = dx; g.ldc = Cin; g.out_mode = OUT_TCONV;
+  return launch_gemm<A_KC_TCONV, B_KS_TAPCLS>(g, 4, ws, ws_bytes, s);
+}
+
+int fl_convT2d_fwd(const float* x, const float* wtp, const float* bias, float* y, int B, int H, int W, int Cin,
+                   int Cout, int act, float act_param, void* ws, size_t ws_bytes, fl_stream_t stream) {
+  FL_REQUIRE(x && wtp && y, "fl_convT2d_fwd: null operand");
+  FL_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "fl_convT2d_fwd: channels must be multiples of 4");
+  GArgs g = base_args();
+  g.M = B * H * W; g.N = Cout; g.K = 4 * Cin;
+  g.A = x; g.a_vec = is_vec(x, Cin);
+  g.H = H; g.W = W; g.Cin = Cin; g.Ho = H; g.Wo = W;
+  g.B = wtp; g.b_vec = is_vec(wtp, Cout); g.b_taps = 16; g.b_Cred = Cin; g.b_Cn = Cout;
+  g.C = y; g.ldc = Cout; g.out_mode = OUT_TCONV;
+  g.bias = bias; g.act = act; g.act_param = act_param;
+  return launch_gemm<A_KC_TCONV, B_KS_TAPCLS>(g, 4, ws, ws_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t fl_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  return fl_gemm_workspace_bytes(Cout, kh * kw * Cin, B * Ho * Wo);
+}
+
+int fl_conv2d_wgrad(const float* dy, const float* x, float* dwp, int B, int H, int W, int Cin, int Cout, int kh,
+                    int kw, int stride, int pad, void* ws, size_t ws_bytes, fl_stream_t stream) {
+  FL_REQUIRE(dy && x && dwp, "fl_conv2d_wgrad: null operand");
+  FL_REQUIRE(Cin % 4 == 0, "fl_conv2d_wgrad: Cin must be a multiple of 4");
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  GArgs g = base_args();
+  // dwp[co][(tap,ci)] = sum_pix dy[pix][co] * x_col[pix][(tap,ci)]
+  g.M = Cout; g.N = kh * kw * Cin; g.K = B * Ho * Wo;
+  g.A = dy; g.lda = Cout; g.a_vec = is_vec(dy, Cout);
+  g.B = x; g.b_vec = is_vec(x, Cin);
+  g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.kw = kw; g.stride = stride; g.pad = pad;
+  g.C = dwp; g.ldc = g.N; g.out_mode = OUT_ROWMAJOR;
+  return launch_gemm<A_KS_PLAIN, B_KS_IM2COL>(g, 1, ws, ws_bytes, reinterpret_cast<hipStream_t>(stream));
+}
+
+int fl_pack_conv_weight(const float* w, float* wp, int O, int I, int kh, int kw, int Ipad, fl_stream_t stream) {
+  FL_REQUIRE(w && wp && Ipad >= I, "fl_pack_conv_weight: bad args");
+  const long long total = (long long)O * kh * kw * Ipad;
+  int blocks = fl::cdiv(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, wp, O, I, kh * kw, Ipad);
+  return fl::check_launch("pack_w_kernel");
+}
+int fl_unpack_conv_weight(const float* wp, float* w, int O, int I, int kh, int kw, int Ipad, fl_stream_t stream) {
+  FL_REQUIRE(w && wp && Ipad >= I, "fl_unpack_conv_weight: bad args");
+  const long long total = (long long)O * I * kh * kw;
+  int blocks = fl::cdiv(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unpack_w_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), wp, w, O, I, kh * kw, Ipad);
+  return fl::check_launch("unpack_w_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,550 @@
+"""Tensor-level wrappers over the C ABI (include/flowers_hip.h).
+
+PyTorch is used for device memory (torch.empty on the current device), the current HIP
+stream and nothing else: every arithmetic op below is a hand-written gfx950 kernel in
+libflowers_hip.so. All tensors are fp32, contiguous, on a CUDA(HIP) device; activations
+are NHWC. Functions raise RuntimeError if the library reports an error; there is no
+fallback.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+
+ACT_NONE, ACT_SWISH, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+KC, KS = 0, 1
+
+_workspaces = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("flowers_hip ops need device tensors (got %s); there is no CPU path" % t.device)
+        if not t.is_contiguous():
+            raise RuntimeError("flowers_hip ops need contiguous tensors")
+
+
+def workspace(nbytes, device=None):
+    """Grow-only per-device scratch buffer (split-K slabs, norm partials)."""
+    device = device if device is not None else torch.cuda.current_device()
+    if isinstance(device, torch.device):
+        device = device.index if device.index is not None else torch.cuda.current_device()
+    nbytes = max(int(nbytes), 1 << 20)
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("workspace would grow during graph capture; run a warm-up step first")
+        ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device="cuda:%d" % device)
+        _workspaces[device] = ws
+    return ws
+
+
+def _ws(nbytes, like):
+    ws = workspace(nbytes, like.device)
+    return ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel())
+
+
+def new(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm(A, B, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, bias=None, bias_scale=1.0, R=None,
+         r_scale=1.0, r_pre=False, act=ACT_NONE, act_param=0.0, out=None):
+    """C[m,n] = epi(sum_k A(m,k) B(n,k)); see flowers_hip.h fl_gemm_f32."""
+    _chk(A, B, bias, R, out)
+    if lda is None:
+        lda = K if a_layout == KC else M
+    if ldb is None:
+        ldb = K if b_layout == KC else N
+    if out is None:
+        out = new((M, N), A)
+    need = _lib.load().fl_gemm_workspace_bytes(M, N, K)
+    wsp, wsn = _ws(min(need, 256 << 20), A)
+    _lib.call("fl_gemm_f32", _p(A), lda, a_layout, _p(B), ldb, b_layout, _p(out), N, M, N, K, _p(bias),
+              float(bias_scale), _p(R), N, float(r_scale), int(r_pre), act, float(act_param), wsp, wsn, _stream())
+    return out
+
+
+def linear(x, w, b=None, act=ACT_NONE, R=None, r_pre=False, bias_scale=1.0, r_scale=1.0, out=None):
+    """nn.Linear forward: x (M,K) @ w(N,K)^T + b."""
+    M, K = x.shape
+    N = w.shape[0]
+    return gemm(x, w, M, N, K, bias=b, act=act, R=R, r_pre=r_pre, bias_scale=bias_scale, r_scale=r_scale, out=out)
+
+
+def linear_dgrad(dy, w, out=None):
+    """dx (M,K) = dy (M,N) @ w (N,K)."""
+    M, N = dy.shape
+    K = w.shape[1]
+    return gemm(dy, w, M, K, N, a_layout=KC, b_layout=KS, lda=N, ldb=K, out=out)
+
+
+def linear_wgrad(dy, x, out=None):
+    """dw (N,K) = dy^T (N,M) @ x (M,K)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    return gemm(dy, x, N, K, M, a_layout=KS, b_layout=KS, lda=N, ldb=K, out=out)
+
+
+def colsum(x, out=None, beta=0.0):
+    M, N = x.shape
+    _chk(x, out)
+    if out is None:
+        out = new((N,), x)
+    wsp, wsn = _ws(_lib.load().fl_colsum_workspace_bytes(M, N), x)
+    _lib.call("fl_colsum", _p(x), N, _p(out), M, N, float(beta), wsp, wsn, _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- conv
+def pack_conv_weight(w, Ipad=None, Opad=None):
+    """(O,I,kh,kw) -> packed [Opad][kh][kw][Ipad] (zero padded)."""
+    _chk(w)
+    O, I, kh, kw = w.shape
+    Ipad = Ipad or I
+    Opad = Opad or O
+    wp = torch.zeros((Opad, kh, kw, Ipad), dtype=torch.float32, device=w.device) if Opad != O else new((O, kh, kw, Ipad), w)
+    _lib.call("fl_pack_conv_weight", _p(w), _p(wp), O, I, kh, kw, Ipad, _stream())
+    return wp
+
+
+def unpack_conv_weight(wp, O, I, kh, kw):
+    _chk(wp)
+    Ipad = wp.shape[3]
+    w = new((O, I, kh, kw), wp)
+    _lib.call("fl_unpack_conv_weight", _p(wp), _p(w), O, I, kh, kw, Ipad, _stream())
+    return w
+
+
+def conv2d_fwd(x, wp, bias, stride, pad, act=ACT_NONE, act_param=0.0, R=None, out_nchw=False, out=None):
+    """x (B,H,W,Cin) NHWC, wp [Cout][kh][kw][Cin] -> (B,Ho,Wo,Cout)."""
+    _chk(x, wp, bias, R, out)
+    B, H, W, Cin = x.shape
+    Cout, kh, kw, _ = wp.shape
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = new((B, Cout, Ho, Wo) if out_nchw else (B, Ho, Wo, Cout), x)
+    need = _lib.load().fl_gemm_workspace_bytes(B * Ho * Wo, Cout, kh * kw * Cin)
+    wsp, wsn = _ws(min(need, 256 << 20), x)
+    _lib.call("fl_conv2d_fwd", _p(x), _p(wp), _p(bias), _p(out), B, H, W, Cin, Cout, kh, kw, stride, pad, act,
+              float(act_param), _p(R), int(out_nchw), wsp, wsn, _stream())
+    return out
+
+
+def conv2d_dgrad(dy, wp, in_hw, stride, pad, out=None):
+    _chk(dy, wp, out)
+    B, Ho, Wo, Cout = dy.shape
+    _, kh, kw, Cin = wp.shape
+    H, W = in_hw
+    if out is None:
+        out = new((B, H, W, Cin), dy)
+    wsp, wsn = _ws(1 << 20, dy)
+    _lib.call("fl_conv2d_dgrad", _p(dy), _p(wp), _p(out), B, H, W, Cin, Cout, kh, kw, stride, pad, wsp, wsn, _stream())
+    return out
+
+
+def conv2d_wgrad(dy, x, kh, kw, stride, pad, out=None):
+    _chk(dy, x, out)
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    if out is None:
+        out = new((Cout, kh, kw, Cin), x)
+    need = _lib.load().fl_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, kh, kw, stride, pad)
+    wsp, wsn = _ws(min(need, 256 << 20), x)
+    _lib.call("fl_conv2d_wgrad", _p(dy), _p(x), _p(out), B, H, W, Cin, Cout, kh, kw, stride, pad, wsp, wsn, _stream())
+    return out
+
+
+def convT2d_fwd(x, wtp, bias, act=ACT_NONE, act_param=0.0, out=None):
+    """ConvTranspose2d(4,2,1): x (B,H,W,Cin), wtp [Cin][4][4][Cout] -> (B,2H,2W,Cout)."""
+    _chk(x, wtp, bias, out)
+    B, H, W, Cin = x.shape
+    Cout = wtp.shape[3]
+    if out is None:
+        out = new((B, 2 * H, 2 * W, Cout), x)
+    wsp, wsn = _ws(1 << 20, x)
+    _lib.call("fl_convT2d_fwd", _p(x), _p(wtp), _p(bias), _p(out), B, H, W, Cin, Cout, act, float(act_param), wsp, wsn,
+              _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- norms
+def _norm_ws(B, HW, C, like):
+    return _ws(_lib.load().fl_norm_workspace_bytes(B, HW, C), like)
+
+
+def instnorm_stats(x, w, b, eps=1e-5):
+    """-> scale, shift, mean, rstd, each (B,C): LayerNorm2d(x) == x*scale + shift."""
+    _chk(x, w, b)
+    B, H, W, C = x.shape
+    scale, shift, mean, rstd = (new((B, C), x) for _ in range(4))
+    wsp, wsn = _norm_ws(B, H * W, C, x)
+    _lib.call("fl_instnorm_stats", _p(x), _p(w), _p(b), float(eps), _p(scale), _p(shift), _p(mean), _p(rstd), B, H * W,
+              C, wsp, wsn, _stream())
+    return scale, shift, mean, rstd
+
+
+def groupnorm_stats(x, w, b, G, eps=1e-5):
+    _chk(x, w, b)
+    B, H, W, C = x.shape
+    scale, shift = new((B, C), x), new((B, C), x)
+    mean, rstd = new((B, G), x), new((B, G), x)
+    wsp, wsn = _norm_ws(B, H * W, C, x)
+    _lib.call("fl_groupnorm_stats", _p(x), _p(w), _p(b), float(eps), G, _p(scale), _p(shift), _p(mean), _p(rstd), B,
+              H * W, C, wsp, wsn, _stream())
+    return scale, shift, mean, rstd
+
+
+def batchnorm_stats(x, w, b, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+    _chk(x, w, b, running_mean, running_var)
+    B, H, W, C = x.shape
+    scale, shift, mean, rstd = (new((C,), x) for _ in range(4))
+    wsp, wsn = _norm_ws(B, H * W, C, x)
+    _lib.call("fl_batchnorm_stats", _p(x), _p(w), _p(b), float(eps), float(momentum), _p(running_mean),
+              _p(running_var), int(training), _p(scale), _p(shift), _p(mean), _p(rstd), B, H * W, C, wsp, wsn, _stream())
+    return scale, shift, mean, rstd
+
+
+def affine_act(x, scale, shift, act=ACT_NONE, act_param=0.0, R=None, out=None):
+    """y = act(x*scale + shift) (+R); scale/shift (B,C) or (C,)."""
+    _chk(x, scale, shift, R, out)
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("fl_affine_act", _p(x), _p(scale), _p(shift), int(scale.dim() == 2), _p(R), _p(out), B, H * W, C, act,
+              float(act_param), _stream())
+    return out
+
+
+def instnorm_bwd(dy, x, scale, shift, w, mean, rstd, act=ACT_NONE, act_param=0.0, need_wb=True):
+    _chk(dy, x, scale, shift, w, mean, rstd)
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    dw = new((C,), x) if need_wb else None
+    db = new((C,), x) if need_wb else None
+    coef = new((3, B, C), x)
+    wsp, wsn = _norm_ws(B, H * W, C, x)
+    _lib.call("fl_instnorm_bwd", _p(dy), _p(x), _p(scale), _p(shift), _p(w), _p(mean), _p(rstd), act, float(act_param),
+              _p(dx), _p(dw), _p(db), _p(coef), B, H * W, C, wsp, wsn, _stream())
+    return dx, dw, db
+
+
+def groupnorm_bwd(dy, x, scale, shift, w, mean, rstd, G, act=ACT_NONE, act_param=0.0):
+    _chk(dy, x, scale, shift, w, mean, rstd)
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    dw, db = new((C,), x), new((C,), x)
+    coef = new((3, B, C), x)
+    wsp, wsn = _norm_ws(B, H * W, C, x)
+    _lib.call("fl_groupnorm_bwd", _p(dy), _p(x), _p(scale), _p(shift), _p(w), _p(mean), _p(rstd), G, act,
+              float(act_param), _p(dx), _p(dw), _p(db), _p(coef), B, H * W, C, wsp, wsn, _stream())
+    return dx, dw, db
+
+
+def batchnorm_bwd(dy, x, scale, shift, w, mean, rstd, act=ACT_NONE, act_param=0.0):
+    _chk(dy, x, scale, shift, w, mean, rstd)
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    dw, db = new((C,), x), new((C,), x)
+    coef = new((3, C), x)
+    wsp, wsn = _norm_ws(B, H * W, C, x)
+    _lib.call("fl_batchnorm_bwd", _p(dy), _p(x), _p(scale), _p(shift), _p(w), _p(mean), _p(rstd), act,
+              float(act_param), _p(dx), _p(dw), _p(db), _p(coef), B, H * W, C, wsp, wsn, _stream())
+    return dx, dw, db
+
+
+def layernorm_fwd(x, w, b, mask=None, eps=1e-5, act=ACT_NONE, act_param=0.0, save=True):
+    """Row LayerNorm: y = act(mask*(xhat*w+b)). -> y, mean, rstd."""
+    _chk(x, w, b, mask)
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    mean = new((rows,), x) if save else None
+    rstd = new((rows,), x) if save else None
+    _lib.call("fl_layernorm_fwd", _p(x), _p(w), _p(b), _p(mask), _p(y), _p(mean), _p(rstd), rows, D, float(eps), act,
+              float(act_param), _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, b, mask, mean, rstd, act=ACT_NONE, act_param=0.0):
+    _chk(dy, x, w, b, mask, mean, rstd)
+    rows, D = x.shape
+    dx = torch.empty_like(x)
+    dw, db = new((D,), x), new((D,), x)
+    wsp, wsn = _ws(_lib.load().fl_layernorm_bwd_workspace_bytes(rows, D), x)
+    _lib.call("fl_layernorm_bwd", _p(dy), _p(x), _p(w), _p(b), _p(mask), _p(mean), _p(rstd), _p(dx), _p(dw), _p(db),
+              rows, D, act, float(act_param), wsp, wsn, _stream())
+    return dx, dw, db
+
+
+# --------------------------------------------------------------------------- residual-block tail
+def res_tail_map(y, scale=None, shift=None, s=None):
+    _chk(y, scale, shift, s)
+    B, H, W, C = y.shape
+    m = new((B, 2, H, W), y)
+    _lib.call("fl_res_tail_map", _p(y), _p(scale), _p(shift), _p(s), _p(m), B, H * W, C, _stream())
+    return m
+
+
+def res_tail_out(y, scale=None, shift=None, s=None, map_=None, saw=None, xres=None, final_swish=False, save_att=False):
+    _chk(y, scale, shift, s, map_, saw, xres)
+    B, H, W, C = y.shape
+    out = torch.empty_like(y)
+    att = new((B, H, W), y) if save_att else None
+    _lib.call("fl_res_tail_out", _p(y), _p(scale), _p(shift), _p(s), _p(map_), _p(saw), _p(xres), _p(out), _p(att), B, H,
+              W, C, int(final_swish), _stream())
+    return (out, att) if save_att else out
+
+
+# --------------------------------------------------------------------------- elementwise & co
+def nchw_to_nhwc(x, Cpad=None):
+    _chk(x)
+    B, C, H, W = x.shape
+    Cpad = Cpad or C
+    y = new((B, H, W, Cpad), x)
+    _lib.call("fl_nchw_to_nhwc", _p(x), _p(y), B, C, H * W, Cpad, _stream())
+    return y
+
+
+def nhwc_to_nchw(x, C=None):
+    _chk(x)
+    B, H, W, Cpad = x.shape
+    C = C or Cpad
+    y = new((B, C, H, W), x)
+    _lib.call("fl_nhwc_to_nchw", _p(x), _p(y), B, C, H * W, Cpad, _stream())
+    return y
+
+
+def act_fwd(x, act, p=0.0, out=None):
+    _chk(x, out)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("fl_act_fwd", _p(x), _p(out), x.numel(), act, float(p), _stream())
+    return out
+
+
+def act_bwd(dy, x, act, p=0.0, out=None):
+    _chk(dy, x, out)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("fl_act_bwd", _p(dy), _p(x), _p(out), x.numel(), act, float(p), _stream())
+    return out
+
+
+def axpby(a, x, b=0.0, y=None, out=None):
+    _chk(x, y, out)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("fl_axpby", float(a), _p(x), float(b), _p(y), _p(out), x.numel(), _stream())
+    return out
+
+
+def scale_heads(v, head_mask, heads, out=None):
+    _chk(v, head_mask, out)
+    B, D = v.shape
+    if out is None:
+        out = torch.empty_like(v)
+    _lib.call("fl_scale_heads", _p(v), _p(head_mask), _p(out), B, D, heads, _stream())
+    return out
+
+
+def add_rows(x, y, out=None):
+    _chk(x, y, out)
+    B, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("fl_add_rows", _p(x), _p(y), y.shape[0], _p(out), B, D, _stream())
+    return out
+
+
+def time_sinusoid(t, n_ch):
+    _chk(t)
+    assert t.dtype == torch.int64
+    out = torch.empty((t.shape[0], n_ch), dtype=torch.float32, device=t.device)
+    _lib.call("fl_time_sinusoid", _p(t), _p(out), t.shape[0], n_ch, _stream())
+    return out
+
+
+def embedding_fwd(table, idx):
+    _chk(table, idx)
+    assert idx.dtype == torch.int64
+    out = new((idx.shape[0], table.shape[1]), table)
+    _lib.call("fl_embedding_fwd", _p(table), _p(idx), _p(out), idx.shape[0], table.shape[1], _stream())
+    return out
+
+
+def embedding_bwd(dout, idx, rows):
+    _chk(dout, idx)
+    dt = new((rows, dout.shape[1]), dout)
+    _lib.call("fl_embedding_bwd", _p(dout), _p(idx), _p(dt), idx.shape[0], dout.shape[1], rows, _stream())
+    return dt
+
+
+def q_sample(x0, eps, t, alpha_bar, out=None):
+    _chk(x0, eps, t, alpha_bar, out)
+    B, D = x0.shape
+    if out is None:
+        out = torch.empty_like(x0)
+    _lib.call("fl_q_sample", _p(x0), _p(eps), _p(t), _p(alpha_bar), _p(out), B, D, _stream())
+    return out
+
+
+def p_sample_update(xt, eps_theta, noise, t_ptr, alpha, alpha_bar, beta, out=None):
+    _chk(xt, eps_theta, noise, t_ptr, alpha, alpha_bar, beta, out)
+    assert t_ptr.dtype == torch.int32
+    if out is None:
+        out = torch.empty_like(xt)
+    _lib.call("fl_p_sample_update", _p(xt), _p(eps_theta), _p(noise), _p(t_ptr), _p(alpha), _p(alpha_bar), _p(beta),
+              _p(out), xt.numel(), _stream())
+    return out
+
+
+def step_counter_add(t32, t64, delta):
+    _lib.call("fl_step_counter_add", _p(t32), _p(t64), int(delta), _stream())
+
+
+def reparameterize(mu, logvar, eps, want_clamped=False):
+    _chk(mu, logvar, eps)
+    z = torch.empty_like(mu) if eps is not None else None
+    lvc = torch.empty_like(mu) if want_clamped else None
+    _lib.call("fl_reparameterize", _p(mu), _p(logvar), _p(eps), _p(z), _p(lvc), mu.numel(), _stream())
+    return z, lvc
+
+
+def philox_fill(out, seed, offset=0, dev_offset=None, mode=0, p=0.0):
+    _chk(out, dev_offset)
+    _lib.call("fl_philox_fill", _p(out), out.numel(), int(seed), int(offset), _p(dev_offset), mode, float(p), _stream())
+    return out
+
+
+def philox_randint(out, seed, hi, offset=0, dev_offset=None):
+    _chk(out, dev_offset)
+    _lib.call("fl_philox_randint", _p(out), out.numel(), int(seed), int(offset), _p(dev_offset), int(hi), _stream())
+    return out
+
+
+def advance_offset(dev_offset, delta):
+    _lib.call("fl_advance_offset", _p(dev_offset), int(delta), _stream())
+
+
+# --------------------------------------------------------------------------- losses / optimizer
+def euclid_loss_fwd(x, y, reduction=1):
+    """-> (loss scalar tensor (1,), per-sample norms (B,))."""
+    _chk(x, y)
+    B = x.shape[0]
+    D = x.numel() // max(B, 1)
+    norms = new((B,), x)
+    loss = new((1,), x)
+    _lib.call("fl_euclid_loss_fwd", _p(x), _p(y), _p(norms), _p(loss), B, D, reduction, _stream())
+    return loss, norms
+
+
+def euclid_loss_bwd(x, y, norms, gscale=1.0, gdev=None, reduction=1, need_dy=False):
+    _chk(x, y, norms, gdev)
+    B = x.shape[0]
+    D = x.numel() // max(B, 1)
+    dx = torch.empty_like(x)
+    dy = torch.empty_like(x) if need_dy else None
+    _lib.call("fl_euclid_loss_bwd", _p(x), _p(y), _p(norms), float(gscale), _p(gdev), _p(dx), _p(dy), B, D, reduction,
+              _stream())
+    return (dx, dy) if need_dy else dx
+
+
+def sqnorm(x, out, accumulate=False):
+    _chk(x, out)
+    wsp, wsn = _ws(_lib.load().fl_sqnorm_workspace_bytes(), x)
+    _lib.call("fl_sqnorm", _p(x), x.numel(), _p(out), int(accumulate), wsp, wsn, _stream())
+    return out
+
+
+def clip_coef(sq, max_norm, coef, norm_out=None):
+    _lib.call("fl_clip_coef", _p(sq), float(max_norm), _p(coef), _p(norm_out), _stream())
+    return coef
+
+
+def adam_step(p, g, m, v, lr_dev, step_dev, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, coef_dev=None, gscale=1.0,
+              decoupled=True):
+    _chk(p, g, m, v, lr_dev, step_dev, coef_dev)
+    _lib.call("fl_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), _p(step_dev), float(b1), float(b2),
+              float(eps), float(wd), _p(coef_dev), float(gscale), int(decoupled), _stream())
+
+
+def kl_fwd(mu, logvar):
+    _chk(mu, logvar)
+    B, D = mu.shape
+    kl_row, musq = new((B,), mu), new((B,), mu)
+    loss = new((1,), mu)
+    _lib.call("fl_kl_fwd", _p(mu), _p(logvar), _p(kl_row), _p(musq), _p(loss), B, D, _stream())
+    return loss, kl_row
+
+
+def kl_bwd(mu, logvar, kl_row, gscale=1.0, gdev=None):
+    _chk(mu, logvar, kl_row, gdev)
+    B, D = mu.shape
+    dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+    _lib.call("fl_kl_bwd", _p(mu), _p(logvar), _p(kl_row), float(gscale), _p(gdev), _p(dmu), _p(dlv), B, D, _stream())
+    return dmu, dlv
+
+
+def bce_fwd(p, target):
+    _chk(p)
+    loss = new((1,), p)
+    _lib.call("fl_bce_fwd", _p(p), float(target), _p(loss), p.numel(), _stream())
+    return loss
+
+
+def bce_bwd(p, target, gscale=1.0, gdev=None):
+    _chk(p, gdev)
+    dp = torch.empty_like(p)
+    _lib.call("fl_bce_bwd", _p(p), float(target), float(gscale), _p(gdev), _p(dp), p.numel(), _stream())
+    return dp
+
+
+def cross_entropy_fwd(logits, labels):
+    _chk(logits, labels)
+    B, C = logits.shape
+    row, probs, loss = new((B,), logits), torch.empty_like(logits), new((1,), logits)
+    _lib.call("fl_cross_entropy_fwd", _p(logits), _p(labels), _p(row), _p(probs), _p(loss), B, C, _stream())
+    return loss, probs
+
+
+def cross_entropy_bwd(probs, labels, gscale=1.0, gdev=None):
+    _chk(probs, labels, gdev)
+    B, C = probs.shape
+    d = torch.empty_like(probs)
+    _lib.call("fl_cross_entropy_bwd", _p(probs), _p(labels), float(gscale), _p(gdev), _p(d), B, C, _stream())
+    return d
+
+
+def gather_rows(table, idx):
+    _chk(table, idx)
+    out = new((idx.shape[0], table.shape[1]), table)
+    _lib.call("fl_gather_rows", _p(table), _p(idx), _p(out), idx.shape[0], table.shape[1], _stream())
+    return out
+
+
+def update_centers(centers, z, labels, momentum=0.9):
+    _chk(centers, z, labels)
+    _lib.call("fl_update_centers", _p(centers), _p(z), _p(labels), float(momentum), z.shape[0], z.shape[1],
+              centers.shape[0], _stream())
+
+
+def balance_losses(terms, weights):
+    _chk(terms, weights)
+    coeff, total = new((6,), terms), new((1,), terms)
+    _lib.call("fl_balance_losses", _p(terms), _p(weights), _p(coeff), _p(total), _stream())
+    return coeff, total

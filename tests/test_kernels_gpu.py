@@ -1,0 +1,357 @@
+"""Kernel-level parity of the C-ABI ops against plain torch fp32 CPU ops (floating point:
+tolerances stated per test; fp32 MFMA is an exact-fp32 fma chain, so only summation order differs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import oxford_102_flower_gan_vae_latent_diffusion_amd.ops as ops  # noqa: E402
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, tol=2e-5):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-12
+    assert err <= tol * max(1.0, ref), "max err %.3e (ref max %.3e)" % (err, ref)
+
+
+def act_ref(x, act):
+    return {0: lambda v: v, 1: lambda v: v * torch.sigmoid(v), 2: F.relu, 3: lambda v: F.leaky_relu(v, 0.2),
+            4: torch.sigmoid}[act](x)
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 70, 36), (256, 256, 256), (256, 1024, 512), (8, 102, 256), (300, 33, 64),
+                                   (256, 256, 4096), (2, 1024, 32768), (1, 1, 8192), (513, 129, 100)])
+def test_gemm_nt(dev, M, N, K):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    bias, R = rnd(N, seed=3), rnd(M, N, seed=4)
+    for act in (0, 1):
+        out = ops.gemm(A.to(dev), B.to(dev), M, N, K, bias=bias.to(dev), R=R.to(dev), act=act, r_scale=0.5)
+        ref = act_ref(A.double() @ B.double().t() + bias.double(), act) + 0.5 * R.double()
+        close(out, ref, tol=1e-5 * max(1, K ** 0.5 / 8))
+    out = ops.gemm(A.to(dev), B.to(dev), M, N, K, bias=bias.to(dev), R=R.to(dev), act=1, r_pre=True, bias_scale=2.0)
+    ref = act_ref(A.double() @ B.double().t() + 2 * bias.double() + R.double(), 1)
+    close(out, ref, tol=1e-5 * max(1, K ** 0.5 / 8))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 256), (64, 102, 256), (8, 256, 512), (256, 1024, 1024), (37, 66, 40)])
+def test_linear_bwd(dev, M, N, K):
+    x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(M, N, seed=3)
+    dx = ops.linear_dgrad(dy.to(dev), w.to(dev))
+    close(dx, dy.double() @ w.double(), tol=2e-5)
+    dw = ops.linear_wgrad(dy.to(dev), x.to(dev))
+    close(dw, dy.double().t() @ x.double(), tol=2e-5)
+    db = ops.colsum(dy.to(dev))
+    close(db, dy.double().sum(0), tol=2e-5)
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 32, 64, 3, 1, 1),
+    (2, 8, 8, 64, 128, 3, 1, 1),
+    (3, 16, 16, 4, 64, 3, 1, 1),
+    (2, 16, 16, 64, 128, 4, 2, 1),
+    (2, 8, 8, 128, 32, 4, 2, 1),
+    (2, 16, 16, 32, 4, 3, 1, 1),
+    (2, 4, 4, 64, 1, 4, 1, 0),
+    (1, 10, 6, 8, 24, 3, 1, 1),
+    (4, 16, 16, 4, 64, 4, 2, 1),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", CONV_CASES)
+def test_conv_fwd_bwd(dev, B, H, W, Cin, Cout, k, s, p):
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, k, k, seed=2, scale=0.1), rnd(Cout, seed=3)
+    xd, bd = nhwc(x).to(dev), b.to(dev)
+    wp = ops.pack_conv_weight(w.to(dev))
+    close(wp, w.permute(0, 2, 3, 1), tol=0)  # pack = permute to [O][kh][kw][I]
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p)
+    y = ops.conv2d_fwd(xd, wp, bd, s, p)
+    close(nchw(y), ref)
+    y2 = ops.conv2d_fwd(xd, wp, bd, s, p, act=ops.ACT_SWISH)
+    close(nchw(y2), act_ref(ref, 1))
+    y3 = ops.conv2d_fwd(xd, wp, bd, s, p, out_nchw=True)
+    close(y3, ref)
+    Rr = rnd(*ref.shape, seed=9)
+    y4 = ops.conv2d_fwd(xd, wp, bd, s, p, R=nhwc(Rr).to(dev))
+    close(nchw(y4), ref + Rr.double())
+    # backward
+    dy = rnd(*ref.shape, seed=5)
+    xg = x.double().requires_grad_(True)
+    wg = w.double().requires_grad_(True)
+    F.conv2d(xg, wg, None, stride=s, padding=p).backward(dy.double())
+    dyd = nhwc(dy).to(dev)
+    dwp = ops.conv2d_wgrad(dyd, xd, k, k, s, p)
+    close(ops.unpack_conv_weight(dwp, Cout, Cin, k, k), wg.grad, tol=3e-5)
+    if Cout % 4 == 0 and (s == 1 or (k == 4 and p == 1)) and k - 1 - p >= 0:
+        dx = ops.conv2d_dgrad(dyd, wp, (H, W), s, p)
+        close(nchw(dx), xg.grad, tol=3e-5)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 8, 64, 32), (2, 4, 4, 128, 64), (3, 8, 8, 32, 64), (1, 16, 16, 128, 64)])
+def test_convT_fwd(dev, B, H, W, Cin, Cout):
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cin, Cout, 4, 4, seed=2, scale=0.1), rnd(Cout, seed=3)
+    ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    wtp = ops.pack_conv_weight(w.to(dev))
+    y = ops.convT2d_fwd(nhwc(x).to(dev), wtp, b.to(dev))
+    close(nchw(y), ref)
+    # ConvT backward = conv forward / conv wgrad with swapped roles
+    dy = rnd(*ref.shape, seed=5)
+    xg, wg = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    F.conv_transpose2d(xg, wg, None, stride=2, padding=1).backward(dy.double())
+    dyd = nhwc(dy).to(dev)
+    dx = ops.conv2d_fwd(dyd, wtp, None, 2, 1)
+    close(nchw(dx), xg.grad, tol=3e-5)
+    dwtp = ops.conv2d_wgrad(nhwc(x).to(dev), dyd, 4, 4, 2, 1)
+    close(ops.unpack_conv_weight(dwtp, Cin, Cout, 4, 4), wg.grad, tol=3e-5)
+
+
+def ln2d_ref(x, w, b, eps=1e-5):
+    mean = x.mean(dim=(2, 3), keepdim=True)
+    var = x.var(dim=(2, 3), keepdim=True, unbiased=False)
+    return (x - mean) / torch.sqrt(var + eps) * w.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 16, 16), (3, 128, 8, 8), (2, 4, 16, 16), (2, 512, 8, 8), (1, 96, 5, 7)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_instnorm(dev, B, C, H, W, act):
+    x = rnd(B, C, H, W, seed=1) * 2 + 0.5
+    w, b, dy = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), rnd(B, C, H, W, seed=4)
+    xg, wg, bg = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = act_ref(ln2d_ref(xg, wg, bg), act)
+    ref.backward(dy.double())
+    xd, wd, bd = nhwc(x).to(dev), w.to(dev), b.to(dev)
+    scale, shift, mean, rstd = ops.instnorm_stats(xd, wd, bd)
+    y = ops.affine_act(xd, scale, shift, act=act)
+    close(nchw(y), ref, tol=2e-5)
+    dx, dw, db = ops.instnorm_bwd(nhwc(dy).to(dev), xd, scale, shift, wd, mean, rstd, act=act)
+    close(nchw(dx), xg.grad, tol=5e-5)
+    close(dw, wg.grad, tol=5e-5)
+    close(db, bg.grad, tol=5e-5)
+
+
+@pytest.mark.parametrize("B,C,H,W,G", [(2, 64, 16, 16, 8), (2, 256, 8, 8, 32), (3, 32, 16, 16, 8)])
+def test_groupnorm(dev, B, C, H, W, G):
+    x = rnd(B, C, H, W, seed=1) * 2 + 0.5
+    w, b, dy = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), rnd(B, C, H, W, seed=4)
+    xg, wg, bg = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = act_ref(F.group_norm(xg, G, wg, bg, 1e-5), 1)
+    ref.backward(dy.double())
+    xd, wd, bd = nhwc(x).to(dev), w.to(dev), b.to(dev)
+    scale, shift, mean, rstd = ops.groupnorm_stats(xd, wd, bd, G)
+    y = ops.affine_act(xd, scale, shift, act=1)
+    close(nchw(y), ref, tol=2e-5)
+    dx, dw, db = ops.groupnorm_bwd(nhwc(dy).to(dev), xd, scale, shift, wd, mean, rstd, G, act=1)
+    close(nchw(dx), xg.grad, tol=5e-5)
+    close(dw, wg.grad, tol=5e-5)
+    close(db, bg.grad, tol=5e-5)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(4, 128, 8, 8), (8, 64, 4, 4)])
+def test_batchnorm(dev, B, C, H, W):
+    x = rnd(B, C, H, W, seed=1) * 2 + 0.5
+    w, b, dy = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), rnd(B, C, H, W, seed=4)
+    rm, rv = 0.1 * rnd(C, seed=5), 1 + 0.1 * rnd(C, seed=6).abs()
+    xg, wg, bg = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    ref = F.leaky_relu(F.batch_norm(xg, rm_ref, rv_ref, wg, bg, True, 0.1, 1e-5), 0.2)
+    ref.backward(dy.double())
+    xd, wd, bd = nhwc(x).to(dev), w.to(dev), b.to(dev)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    scale, shift, mean, rstd = ops.batchnorm_stats(xd, wd, bd, rmd, rvd, True)
+    y = ops.affine_act(xd, scale, shift, act=3, act_param=0.2)
+    close(nchw(y), ref, tol=2e-5)
+    close(rmd, rm_ref, tol=2e-6)
+    close(rvd, rv_ref, tol=2e-6)
+    dx, dw, db = ops.batchnorm_bwd(nhwc(dy).to(dev), xd, scale, shift, wd, mean, rstd, act=3, act_param=0.2)
+    close(nchw(dx), xg.grad, tol=5e-5)
+    close(dw, wg.grad, tol=5e-5)
+    close(db, bg.grad, tol=5e-5)
+    # eval mode uses running stats
+    scale, shift, _, _ = ops.batchnorm_stats(xd, wd, bd, rmd, rvd, False)
+    y = ops.affine_act(xd, scale, shift)
+    close(nchw(y), F.batch_norm(x.double(), rm_ref, rv_ref, w.double(), b.double(), False, 0.1, 1e-5), tol=2e-5)
+
+
+@pytest.mark.parametrize("rows,D", [(8, 256), (256, 1024), (4, 32768), (3, 512)])
+def test_layernorm(dev, rows, D):
+    x = rnd(rows, D, seed=1) * 2 + 0.3
+    w, b, dy = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3), rnd(rows, D, seed=4)
+    mask = (torch.rand(rows, D, generator=torch.Generator().manual_seed(7)) > 0.3).float() / 0.7
+    for use_mask in (False, True):
+        xg, wg, bg = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+        u = F.layer_norm(xg, (D,), wg, bg, 1e-5)
+        if use_mask:
+            u = u * mask.double()
+        ref = act_ref(u, 1)
+        ref.backward(dy.double())
+        md = mask.to(dev) if use_mask else None
+        y, mean, rstd = ops.layernorm_fwd(x.to(dev), w.to(dev), b.to(dev), mask=md, act=1)
+        close(y, ref, tol=2e-5)
+        dx, dw, db = ops.layernorm_bwd(dy.to(dev), x.to(dev), w.to(dev), b.to(dev), md, mean, rstd, act=1)
+        close(dx, xg.grad, tol=5e-5)
+        close(dw, wg.grad, tol=5e-5)
+        close(db, bg.grad, tol=5e-5)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 128, 8, 8), (2, 512, 4, 4), (1, 32, 16, 16), (2, 256, 8, 8)])
+def test_res_tail(dev, B, C, H, W):
+    y, xres = rnd(B, C, H, W, seed=1), rnd(B, C, H, W, seed=2)
+    scale, shift, s = 1 + 0.1 * rnd(B, C, seed=3), 0.1 * rnd(B, C, seed=4), torch.sigmoid(rnd(B, C, seed=5))
+    saw = rnd(1, 2, 7, 7, seed=6, scale=0.2)
+    u = (y.double() * scale.double().view(B, C, 1, 1) + shift.double().view(B, C, 1, 1)) * s.double().view(B, C, 1, 1)
+    m = torch.cat([u.mean(1, keepdim=True), u.max(1, keepdim=True)[0]], 1)
+    att = torch.sigmoid(F.conv2d(m, saw.double(), padding=3))
+    ref = act_ref(u * att + xres.double(), 1)
+    yd = nhwc(y).to(dev)
+    mp = ops.res_tail_map(yd, scale.to(dev), shift.to(dev), s.to(dev))
+    close(mp, m, tol=1e-5)
+    out, att_d = ops.res_tail_out(yd, scale.to(dev), shift.to(dev), s.to(dev), mp, saw.to(dev).contiguous(),
+                                  nhwc(xres).to(dev), final_swish=True, save_att=True)
+    close(nchw(out), ref, tol=2e-5)
+    close(att_d, att[:, 0], tol=1e-5)
+    # identity forms (stand-alone CALayer / SpatialAttention)
+    out2 = ops.res_tail_out(yd, None, None, s.to(dev))
+    close(nchw(out2), y.double() * s.double().view(B, C, 1, 1), tol=1e-6)
+
+
+def test_elementwise_and_layout(dev):
+    x = rnd(3, 3, 8, 8, seed=1)
+    y = ops.nchw_to_nhwc(x.to(dev), 4)
+    assert y.shape == (3, 8, 8, 4)
+    close(y[..., :3], x.permute(0, 2, 3, 1), tol=0)
+    assert float(y[..., 3].abs().max()) == 0.0
+    close(ops.nhwc_to_nchw(y, 3), x, tol=0)
+    v = rnd(1000, seed=2) * 3
+    for act in (1, 2, 3, 4):
+        vg = v.double().requires_grad_(True)
+        r = act_ref(vg, act)
+        r.sum().backward()
+        close(ops.act_fwd(v.to(dev), act, 0.2), r, tol=1e-6)
+        close(ops.act_bwd(torch.ones_like(v).to(dev), v.to(dev), act, 0.2), vg.grad, tol=1e-6)
+    a, b = rnd(100, seed=3), rnd(100, seed=4)
+    close(ops.axpby(2.0, a.to(dev), -0.5, b.to(dev)), 2 * a - 0.5 * b, tol=1e-6)
+
+
+def test_embeddings_and_diffusion_ops(dev):
+    import math
+    t = torch.tensor([0, 1, 17, 500, 999], dtype=torch.int64)
+    half = 128
+    emb = math.log(10000) / (half - 1)
+    f = torch.exp(torch.arange(half) * -emb)
+    e = t[:, None] * f[None, :]
+    ref = torch.cat((e.sin(), e.cos()), dim=1)
+    close(ops.time_sinusoid(t.to(dev), 256), ref, tol=2e-6)
+    table, idx = rnd(102, 256, seed=1), torch.tensor([5, 5, 101, 0, 7, 5], dtype=torch.int64)
+    close(ops.embedding_fwd(table.to(dev), idx.to(dev)), table[idx], tol=0)
+    dout = rnd(6, 256, seed=2)
+    dt = torch.zeros(102, 256).index_add_(0, idx, dout)
+    close(ops.embedding_bwd(dout.to(dev), idx.to(dev), 102), dt, tol=1e-6)
+    beta = torch.linspace(0.0001, 0.02, 1000)
+    alpha = 1 - beta
+    ab = torch.cumprod(alpha, 0)
+    x0, eps = rnd(5, 256, seed=3), rnd(5, 256, seed=4)
+    ref = torch.sqrt(ab[t].reshape(-1, 1)) * x0 + torch.sqrt(1 - ab[t].reshape(-1, 1)) * eps
+    close(ops.q_sample(x0.to(dev), eps.to(dev), t.to(dev), ab.to(dev)), ref, tol=1e-6)
+    for tt in (999, 1, 0):
+        tp = torch.tensor([tt], dtype=torch.int32, device=dev)
+        et, nz = rnd(5, 256, seed=5), rnd(5, 256, seed=6)
+        mean = (x0 - ((1 - alpha[tt]) / torch.sqrt(1 - ab[tt])) * et) / torch.sqrt(alpha[tt])
+        ref = mean + torch.sqrt(beta[tt]) * nz if tt > 0 else mean
+        out = ops.p_sample_update(x0.to(dev), et.to(dev), nz.to(dev), tp, alpha.to(dev), ab.to(dev), beta.to(dev))
+        close(out, ref, tol=1e-6)
+    mu, lv = rnd(4, 256, seed=7), rnd(4, 256, seed=8) * 4
+    z, lvc = ops.reparameterize(mu.to(dev), lv.to(dev), eps[:4].contiguous().to(dev), want_clamped=True)
+    lvr = torch.clamp(lv, -2.0, 10.0)
+    close(lvc, lvr, tol=0)
+    close(z, mu + eps[:4] * torch.exp(0.5 * lvr), tol=1e-6)
+
+
+def test_philox(dev):
+    out = torch.empty(1 << 20, device=dev)
+    ops.philox_fill(out, seed=1234, mode=0)
+    assert abs(float(out.mean())) < 5e-3 and abs(float(out.std()) - 1.0) < 5e-3
+    out2 = torch.empty(1 << 20, device=dev)
+    ops.philox_fill(out2, seed=1234, mode=0)
+    assert torch.equal(out, out2)
+    ops.philox_fill(out2, seed=1234, offset=1 << 18, mode=0)
+    assert not torch.equal(out, out2)
+    m = torch.empty(1 << 20, device=dev)
+    ops.philox_fill(m, seed=7, mode=1, p=0.3)
+    keep = float((m > 0).float().mean())
+    assert abs(keep - 0.7) < 5e-3
+    assert abs(float(m.max()) - 1 / 0.7) < 1e-6
+    r = torch.empty(1 << 16, dtype=torch.int64, device=dev)
+    ops.philox_randint(r, seed=3, hi=1000)
+    assert int(r.min()) >= 0 and int(r.max()) <= 999 and abs(float(r.float().mean()) - 499.5) < 10
+
+
+def test_losses_and_optimizer(dev):
+    x, y = rnd(6, 3, 8, 8, seed=1), rnd(6, 3, 8, 8, seed=2)
+    xg = x.double().requires_grad_(True)
+    ref = torch.sqrt(((xg - y.double()) ** 2).view(6, -1).sum(1) + 1e-8).mean()
+    ref.backward()
+    loss, norms = ops.euclid_loss_fwd(x.to(dev), y.to(dev))
+    close(loss, ref.reshape(1), tol=1e-6)
+    close(ops.euclid_loss_bwd(x.to(dev), y.to(dev), norms), xg.grad, tol=1e-6)
+    # KL
+    mu, lv = rnd(5, 256, seed=3) * 4, rnd(5, 256, seed=4) * 3
+    mug, lvg = mu.double().requires_grad_(True), lv.double().requires_grad_(True)
+    m_, l_ = torch.clamp(mug, -10, 10), torch.clamp(lvg, -2, 10)
+    kl = torch.clamp(-0.5 * torch.sum(1 + l_ - m_.pow(2) - l_.exp(), dim=1), 0, 100).mean() + 1e-4 * torch.sum(m_.pow(2))
+    kl.backward()
+    loss, kl_row = ops.kl_fwd(mu.to(dev), lv.to(dev))
+    close(loss, kl.reshape(1), tol=2e-6)
+    dmu, dlv = ops.kl_bwd(mu.to(dev), lv.to(dev), kl_row)
+    close(dmu, mug.grad, tol=2e-6)
+    close(dlv, lvg.grad, tol=2e-6)
+    # BCE
+    p = torch.sigmoid(rnd(16, seed=5))
+    for tgt in (0.0, 1.0):
+        pg = p.double().requires_grad_(True)
+        r = F.binary_cross_entropy(pg, torch.full_like(pg, tgt))
+        r.backward()
+        close(ops.bce_fwd(p.to(dev), tgt), r.reshape(1), tol=1e-6)
+        close(ops.bce_bwd(p.to(dev), tgt), pg.grad, tol=1e-6)
+    # CE
+    lg, lab = rnd(7, 102, seed=6) * 3, torch.randint(0, 102, (7,), generator=torch.Generator().manual_seed(1))
+    lgg = lg.double().requires_grad_(True)
+    r = F.cross_entropy(lgg, lab)
+    r.backward()
+    loss, probs = ops.cross_entropy_fwd(lg.to(dev), lab.to(dev))
+    close(loss, r.reshape(1), tol=1e-6)
+    close(ops.cross_entropy_bwd(probs, lab.to(dev)), lgg.grad, tol=1e-6)
+    # clip + AdamW vs torch.optim
+    n = 10007
+    p0, g0 = rnd(n, seed=7), rnd(n, seed=8) * 3
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=1e-5, betas=(0.9, 0.999))
+    pd, md, vd = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    lr_dev, step_dev = torch.tensor([1e-3], device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    sq, coef, nrm = torch.zeros(1, device=dev), torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    for it in range(3):
+        g = g0 * (it + 1)
+        pr.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        gd = g.to(dev)
+        ops.sqnorm(gd, sq)
+        ops.clip_coef(sq, 1.0, coef, nrm)
+        ops.step_counter_add(step_dev, None, 1)
+        ops.adam_step(pd, gd, md, vd, lr_dev, step_dev, wd=1e-5, coef_dev=coef)
+        close(nrm, tn.reshape(1), tol=1e-5)
+        close(pd, pr.data, tol=2e-6)
