@@ -160,7 +160,8 @@ int fl_axpby(float a, const float* x, float b, const float* y, float* out, int64
 /* attention-dropout of nn.MultiheadAttention on a length-1 sequence (v2:514,550-551) */
 int fl_scale_heads(const float* v, const float* head_mask, float* out, int B, int D, int heads, fl_stream_t stream);
 int fl_add_rows(const float* x, const float* y, int y_rows, float* out, int B, int D, fl_stream_t stream);
-int fl_time_sinusoid(const int64_t* t, float* out, int Bt, int n_ch, fl_stream_t stream);           /* v2:410-414 */
+/* freqs[n_ch/2] = exp(-i*ln(1e4)/(n_ch/2-1)), the constant table of v2:411-412 */
+int fl_time_sinusoid(const int64_t* t, const float* freqs, float* out, int Bt, int n_ch, fl_stream_t stream); /* v2:410-414 */
 int fl_embedding_fwd(const float* table, const int64_t* idx, float* out, int n, int D, fl_stream_t stream); /* v2:430 */
 int fl_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, int n, int D, int rows, fl_stream_t stream);
 int fl_q_sample(const float* x0, const float* eps, const int64_t* t, const float* alpha_bar, float* xt, int B, int D,

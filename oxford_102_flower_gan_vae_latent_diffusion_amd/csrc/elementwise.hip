@@ -80,16 +80,17 @@ __global__ void add_rows_kernel(const float* __restrict__ x, const float* __rest
 }
 
 // ---- embeddings --------------------------------------------------------------
-// sinusoidal time features (v2:410-414): [sin(t*f_i), cos(t*f_i)], f_i = exp(-i*ln(1e4)/(half-1))
-__global__ void time_sinusoid_kernel(const long long* __restrict__ t, float* __restrict__ out, int Bt, int n_ch) {
+// sinusoidal time features (v2:410-414): [sin(t*f_i), cos(t*f_i)]. The constant table
+// f_i = exp(-i*ln(1e4)/(half-1)) is an input (computed once by the host exactly as v2:411-412):
+// a 1-ulp difference in f_i would be amplified ~1000x by t.
+__global__ void time_sinusoid_kernel(const long long* __restrict__ t, const float* __restrict__ freqs,
+                                     float* __restrict__ out, int Bt, int n_ch) {
   const int half = n_ch / 2;
   const long long n = (long long)Bt * half;
-  const float k = logf(10000.0f) / (float)(half - 1);
   GRID_STRIDE(i, n) {
     const int j = (int)(i % half);
     const int b = (int)(i / half);
-    const float f = expf((float)j * -k);
-    const float a = (float)t[b] * f;
+    const float a = (float)t[b] * freqs[j];
     out[(long long)b * n_ch + j] = sinf(a);
     out[(long long)b * n_ch + half + j] = cosf(a);
   }
@@ -294,11 +295,11 @@ int fl_add_rows(const float* x, const float* y, int y_rows, float* out, int B, i
   hipLaunchKernelGGL(add_rows_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), x, y, y_rows, out, B, D);
   return fl::check_launch("add_rows");
 }
-int fl_time_sinusoid(const int64_t* t, float* out, int Bt, int n_ch, fl_stream_t stream) {
-  FL_REQUIRE(n_ch % 2 == 0 && n_ch >= 4, "fl_time_sinusoid: n_ch must be even");
+int fl_time_sinusoid(const int64_t* t, const float* freqs, float* out, int Bt, int n_ch, fl_stream_t stream) {
+  FL_REQUIRE(n_ch % 2 == 0 && n_ch >= 4 && freqs, "fl_time_sinusoid: n_ch must be even, freqs non-null");
   const long long n = (long long)Bt * (n_ch / 2);
   if (!n) return FL_OK;
-  hipLaunchKernelGGL(time_sinusoid_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), (const long long*)t, out, Bt, n_ch);
+  hipLaunchKernelGGL(time_sinusoid_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), (const long long*)t, freqs, out, Bt, n_ch);
   return fl::check_launch("time_sinusoid");
 }
 int fl_embedding_fwd(const float* table, const int64_t* idx, float* out, int n, int D, fl_stream_t stream) {

@@ -371,11 +371,19 @@ def add_rows(x, y, out=None):
     return out
 
 
-def time_sinusoid(t, n_ch):
-    _chk(t)
+def time_freqs(n_ch, device):
+    """Constant frequency table of v2:411-412, computed on the host exactly as the reference does."""
+    import math
+    half = n_ch // 2
+    return torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(device)
+
+
+def time_sinusoid(t, freqs):
+    _chk(t, freqs)
     assert t.dtype == torch.int64
+    n_ch = 2 * freqs.shape[0]
     out = torch.empty((t.shape[0], n_ch), dtype=torch.float32, device=t.device)
-    _lib.call("fl_time_sinusoid", _p(t), _p(out), t.shape[0], n_ch, _stream())
+    _lib.call("fl_time_sinusoid", _p(t), _p(freqs), _p(out), t.shape[0], n_ch, _stream())
     return out
 
 

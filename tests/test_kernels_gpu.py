@@ -255,7 +255,7 @@ def test_embeddings_and_diffusion_ops(dev):
     f = torch.exp(torch.arange(half) * -emb)
     e = t[:, None] * f[None, :]
     ref = torch.cat((e.sin(), e.cos()), dim=1)
-    close(ops.time_sinusoid(t.to(dev), 256), ref, tol=2e-6)
+    close(ops.time_sinusoid(t.to(dev), ops.time_freqs(256, dev)), ref, tol=2e-6)
     table, idx = rnd(102, 256, seed=1), torch.tensor([5, 5, 101, 0, 7, 5], dtype=torch.int64)
     close(ops.embedding_fwd(table.to(dev), idx.to(dev)), table[idx], tol=0)
     dout = rnd(6, 256, seed=2)
