@@ -1,0 +1,222 @@
+"""bench.py — images/sec of the latent-DDPM training step (BASELINE.json metric: "images/sec VAE+UNet train
+step, 64x64 bs256"): frozen-encoder forward + reparameterize + q_sample + denoiser fwd/bwd + clip + AdamW
+(+ one RCCL all-reduce of the flat gradient buffer per step when N > 1), v2:1254-1264.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver as torch.distributed.run (one rank per GPU, RCCL). Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
+# algorithmic GFLOP per image (forward MACs x2): frozen encoder fwd + denoiser fwd+bwd (3x fwd)
+GFLOP_PER_IMAGE_STEP = 2.748
+
+
+def conv_shapes(B):
+    """The launches of the dominant kernel gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> in one step:
+    (name, B,H,W,Cin,Cout,k,stride,pad). Algorithmic FLOP per launch = 2*B*Ho*Wo*Cout*k*k*Cin."""
+    s = []
+    for i, (C, H) in enumerate(((128, 32), (256, 16), (512, 8))):
+        s.append(("down%d 4x4s2" % (i + 1), B, 2 * H, 2 * H, C // 2, C, 4, 2, 1))
+        s.append(("res%d.conv1 3x3" % (i + 1), B, H, H, C, C, 3, 1, 1))
+        s.append(("res%d.conv2 3x3" % (i + 1), B, H, H, C, C, 3, 1, 1))
+    return s
+
+
+def measure_dominant_kernel(dev, B, reps=5):
+    """HIP-event timing (on the stream the kernels are launched on = torch's current stream) of every launch of
+    the dominant kernel in one step -> average duration per launch and algorithmic TFLOP/s."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
+    tot_t, tot_f, n = 0.0, 0.0, 0
+    per = []
+    for name, b, H, W, Ci, Co, k, s, p in conv_shapes(B):
+        x = torch.empty(b, H, W, Ci, device=dev)
+        ops.philox_fill(x, seed=11, mode=0)
+        w = torch.empty(Co, k, k, Ci, device=dev)
+        ops.philox_fill(w, seed=12, mode=0)
+        bias = torch.zeros(Co, device=dev)
+        Ho = (H + 2 * p - k) // s + 1
+        y = torch.empty(b, Ho, Ho, Co, device=dev)
+        ops.conv2d_fwd(x, w, bias, s, p, out=y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.conv2d_fwd(x, w, bias, s, p, out=y)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fl = 2.0 * b * Ho * Ho * Co * k * k * Ci
+        per.append((name, ms, fl / ms / 1e9))
+        tot_t += ms
+        tot_f += fl
+        n += 1
+    return dict(avg_ms=tot_t / n, tflops=tot_f / tot_t / 1e9, flop_per_launch=tot_f / n, launches=n, per=per)
+
+
+def cpu_baseline(threads, B=32, iters=6):
+    """The CPU oracle (validated restatement of the reference's step, same torch-CPU ops) timed on this box's
+    host cores on a bounded sample of the same workload. Checker code: imported only here."""
+    from oracle import procedural_init as pinit
+    from oracle import v2_oracle as O
+    import json as _json
+    shapes = _json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_shapes.json")))
+    torch.set_num_threads(threads)
+    ae_sd = pinit.procedural_state_dict(shapes["autoencoder"], 42)
+    un_sd = pinit.procedural_state_dict(shapes["unet"], 44)
+    g = torch.Generator().manual_seed(0)
+    data, labels = torch.rand(B, 3, 64, 64, generator=g), torch.randint(0, 102, (B,), generator=g)
+    re, t, eps = torch.randn(B, 256, generator=g), torch.randint(0, 1000, (B,), generator=g), torch.randn(B, 256, generator=g)
+    O.ddpm_step(ae_sd, un_sd, data, labels, re, t, eps)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        O.ddpm_step(ae_sd, un_sd, data, labels, re, t, eps)
+    dt = time.perf_counter() - t0
+    return dict(value=B * iters / dt, unit="images/s", cores=threads, kind="port",
+                sample="%d steps of the v2 latent-DDPM step at batch %d (oracle.ddpm_step, fp32, torch %s)" % (iters, B, torch.__version__))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE metric: 256)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pg = dist.group.WORLD
+
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import ops, steps
+
+    torch.manual_seed(1234)  # identical initial weights on every rank (random init of the v2 architecture)
+    ae = M.SimpleAutoencoder().to(dev).eval()
+    un = M.ConditionalUNet().to(dev).train()  # the reference trains the denoiser in train() mode (dropout active)
+    un.rng.manual_seed(44 + rank)
+    ae.rng.manual_seed(42 + rank)
+    tr = steps.DDPMTrainer(ae, un, lr=1e-3, process_group=pg, world_size=world)
+    tr.diffusion.rng.manual_seed(1234 + rank)
+
+    B = a.batch
+    nb = 4  # distinct synthetic Flowers-shaped batches resident in HBM (seed offset = rank)
+    batches, labels = [], []
+    for i in range(nb):
+        d = torch.empty(B, 3, 64, 64, device=dev)
+        ops.philox_fill(d, seed=2000 + 97 * rank + i, mode=2)
+        l = torch.empty(B, dtype=torch.int64, device=dev)
+        ops.philox_randint(l, seed=3000 + 97 * rank + i, hi=102)
+        batches.append(d)
+        labels.append(l)
+    sdata, slabels = batches[0].clone(), labels[0].clone()
+
+    use_graph = not a.no_graph
+    if use_graph:
+        tr.capture(sdata, slabels)
+
+    def one_step(i):
+        if use_graph:
+            sdata.copy_(batches[i % nb])
+            slabels.copy_(labels[i % nb])
+            return tr.replay()
+        return tr.step(batches[i % nb], labels[i % nb])
+
+    for i in range(a.warmup):
+        one_step(i)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = one_step(i)
+    torch.cuda.synchronize(dev)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    final_loss = float(loss)
+    assert final_loss == final_loss, "loss is NaN"
+
+    out = {
+        "metric": "images/sec VAE+UNet train step, 64x64 bs256",
+        "value": world * B * a.steps / dt,
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1000.0 * dt / a.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[2]/[3]: v2 latent-DDPM eps-prediction training step on frozen-VAE "
+                        "latents (encoder fwd + U-Net fwd/bwd + clip + AdamW), 102-class cond, 64x64x3 synthetic "
+                        "Flowers-shaped batches, batch %d per GPU, random-init weights" % B,
+            "global_batch": world * B,
+            "parallelism": "dp%d" % world,
+            "hipgraph": use_graph,
+            "loss": final_loss,
+        },
+    }
+    if rank == 0 and world == 1:
+        if not a.no_roofline:
+            r = measure_dominant_kernel(dev, B)
+            out["roofline"] = {
+                "bound": "mfma",
+                "kernel": "gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+                "achieved": r["tflops"],
+                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": r["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "avg_launch_ms": r["avg_ms"],
+                "algorithmic_gflop_per_launch": r["flop_per_launch"] / 1e9,
+                "launches_per_step": r["launches"],
+                "step_frac_of_mfma_roofline": (GFLOP_PER_IMAGE_STEP * B * a.steps / dt / 1e3) / FP32_MFMA_PEAK_TFLOPS,
+            }
+        if not a.no_cpu_baseline:
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(threads)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

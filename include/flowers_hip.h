@@ -131,21 +131,23 @@ int fl_batchnorm_bwd(const float* dy, const float* x, const float* scale, const 
                      const float* mean, const float* rstd, int act, float act_param, float* dx, float* dw, float* db,
                      float* coef, int B, int HW, int C, void* ws, size_t ws_bytes, fl_stream_t stream);
 /* nn.LayerNorm over the last dim (v2:212,218,248,251,313,317,521,525,530):
- * y = act(mask * (xhat*w + b)); mask (rows,D) optional = dropout scale (v2:522). */
-int fl_layernorm_fwd(const float* x, const float* w, const float* b, const float* mask, float* y, float* mean,
-                     float* rstd, int rows, int D, float eps, int act, float act_param, fl_stream_t stream);
+ * y = act(mask * (xhat*w + b)) + R; mask (rows,D) optional = dropout scale (v2:522);
+ * R optional residual (v2:548).  Backward: dx = LN'(dy) + R. */
+int fl_layernorm_fwd(const float* x, const float* w, const float* b, const float* mask, const float* R, float* y,
+                     float* mean, float* rstd, int rows, int D, float eps, int act, float act_param, fl_stream_t stream);
 size_t fl_layernorm_bwd_workspace_bytes(int rows, int D);
 int fl_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mask,
-                     const float* mean, const float* rstd, float* dx, float* dw, float* db, int rows, int D, int act,
-                     float act_param, void* ws, size_t ws_bytes, fl_stream_t stream);
+                     const float* mean, const float* rstd, const float* R, float* dx, float* dw, float* db, int rows, int D,
+                     int act, float act_param, void* ws, size_t ws_bytes, fl_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Residual-block tail: CALayer (v2:53-67) x SpatialAttention (v2:69-81) x residual+Swish
  * (v2:176-177) fused into two streaming passes.  u = s[b,c]*(y*scale[b,c]+shift[b,c]).
  * ------------------------------------------------------------------------ */
-int fl_res_tail_map(const float* y, const float* scale, const float* shift, const float* s, float* map, int B, int HW,
-                    int C, fl_stream_t stream);
-int fl_res_tail_out(const float* y, const float* scale, const float* shift, const float* s, const float* map,
+int fl_res_tail_map(const float* y, const float* scale, const float* shift, const float* s, int s_per_image, float* map,
+                    int B, int HW, int C, fl_stream_t stream);
+int fl_res_tail_out(const float* y, const float* scale, const float* shift, const float* s, int s_per_image,
+                    const float* map,
                     const float* saw, const float* xres, float* out, float* att_out, int B, int H, int W, int C,
                     int final_swish, fl_stream_t stream);
 
@@ -179,8 +181,13 @@ int fl_philox_randint(int64_t* out, int64_t n, uint64_t seed, uint64_t offset, c
                       fl_stream_t stream);
 int fl_advance_offset(int64_t* dev_offset, int64_t delta, fl_stream_t stream);
 size_t fl_colsum_workspace_bytes(int M, int N);
-int fl_colsum(const float* x, int64_t ldx, float* out, int M, int N, float beta, void* ws, size_t ws_bytes,
+/* out = beta*out + alpha * column sums of x (M,N): bias gradients */
+int fl_colsum(const float* x, int64_t ldx, float* out, int M, int N, float alpha, float beta, void* ws, size_t ws_bytes,
               fl_stream_t stream);
+/* out = a + sigmoid(w[0])*b (learned residual gate v2:533,561; w stays on the device); a may be NULL */
+int fl_gated_add(const float* a, const float* b, const float* w, float* out, int64_t n, fl_stream_t stream);
+/* out[0] = sigmoid'(w[0]) * sum(x*y): gradient of the gate parameter */
+int fl_gate_grad(const float* x, const float* y, const float* w, float* out, int64_t n, fl_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Losses + optimizer tail (device-resident scalars; no host syncs)

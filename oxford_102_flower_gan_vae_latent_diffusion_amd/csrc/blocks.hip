@@ -28,14 +28,14 @@ __device__ __forceinline__ float group_max(float v) {
 
 // u for 4 channels
 __device__ __forceinline__ float4 tail_u(const float* y, const float* scale, const float* shift, const float* s,
-                                         long long pix_off, long long bc_off) {
+                                         long long pix_off, long long bc_off, long long s_off) {
   float4 v = ld4(y + pix_off);
   if (scale) {
     const float4 sc = ld4(scale + bc_off), sh = ld4(shift + bc_off);
     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
   }
   if (s) {
-    const float4 ss = ld4(s + bc_off);
+    const float4 ss = ld4(s + s_off);
     v.x *= ss.x; v.y *= ss.y; v.z *= ss.z; v.w *= ss.w;
   }
   return v;
@@ -44,7 +44,7 @@ __device__ __forceinline__ float4 tail_u(const float* y, const float* scale, con
 template <int LPP>
 __global__ void res_tail_map_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                     const float* __restrict__ shift, const float* __restrict__ s,
-                                    float* __restrict__ map, int B, int HW, int C) {
+                                    float* __restrict__ map, int B, int HW, int C, int s_per_image) {
   constexpr int PPW = 64 / LPP;  // pixels per wave
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int gl = lane % LPP, gp = lane / LPP;
@@ -59,7 +59,7 @@ __global__ void res_tail_map_kernel(const float* __restrict__ y, const float* __
     const int b = (int)(pp / HW);
     float sum = 0.f, mx = -INFINITY;
     for (int c4 = gl; c4 < C4; c4 += LPP) {
-      const float4 u = tail_u(y, scale, shift, s, pp * C + c4 * 4, (long long)b * C + c4 * 4);
+      const float4 u = tail_u(y, scale, shift, s, pp * C + c4 * 4, (long long)b * C + c4 * 4, (s_per_image ? (long long)b * C : 0) + c4 * 4);
       sum += (u.x + u.y) + (u.z + u.w);
       mx = fmaxf(fmaxf(mx, fmaxf(u.x, u.y)), fmaxf(u.z, u.w));
     }
@@ -78,7 +78,7 @@ __global__ void res_tail_out_kernel(const float* __restrict__ y, const float* __
                                     const float* __restrict__ shift, const float* __restrict__ s,
                                     const float* __restrict__ map, const float* __restrict__ saw,
                                     const float* __restrict__ xres, float* __restrict__ out, float* __restrict__ att_out,
-                                    int B, int H, int W, int C, int final_swish) {
+                                    int B, int H, int W, int C, int final_swish, int s_per_image) {
   constexpr int PPW = 64 / LPP;
   __shared__ float wsm[98];
   if (map) {
@@ -116,7 +116,7 @@ __global__ void res_tail_out_kernel(const float* __restrict__ y, const float* __
     if (!ok) continue;
     for (int c4 = gl; c4 < C4; c4 += LPP) {
       const long long off = pp * C + c4 * 4;
-      float4 u = tail_u(y, scale, shift, s, off, (long long)b * C + c4 * 4);
+      float4 u = tail_u(y, scale, shift, s, off, (long long)b * C + c4 * 4, (s_per_image ? (long long)b * C : 0) + c4 * 4);
       u.x *= att; u.y *= att; u.z *= att; u.w *= att;
       if (xres) {
         const float4 r = ld4(xres + off);
@@ -144,7 +144,7 @@ extern "C" {
 
 // map (B,2,H*W): plane 0 = channel mean, plane 1 = channel max of u = s*(y*scale+shift)
 // (scale/shift/s may be NULL = identity).  Replaces v2:76-78 (+ v2:151-155, v2:67 fused in).
-int fl_res_tail_map(const float* y, const float* scale, const float* shift, const float* s, float* map, int B, int HW,
+int fl_res_tail_map(const float* y, const float* scale, const float* shift, const float* s, int s_per_image, float* map, int B, int HW,
                     int C, fl_stream_t stream) {
   FL_REQUIRE(y && map && C % 4 == 0, "fl_res_tail_map: bad args");
   FL_REQUIRE((scale == nullptr) == (shift == nullptr), "fl_res_tail_map: scale/shift must come together");
@@ -152,7 +152,7 @@ int fl_res_tail_map(const float* y, const float* scale, const float* shift, cons
   const long long npix = (long long)B * HW;
   if (npix == 0) return FL_OK;
   const int C4 = C / 4;
-#define LAUNCH_MAP(L) hipLaunchKernelGGL(res_tail_map_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, B, HW, C)
+#define LAUNCH_MAP(L) hipLaunchKernelGGL(res_tail_map_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, B, HW, C, s_per_image)
   if (C4 >= 64) LAUNCH_MAP(64);
   else if (C4 >= 32) LAUNCH_MAP(32);
   else if (C4 >= 16) LAUNCH_MAP(16);
@@ -164,7 +164,7 @@ int fl_res_tail_map(const float* y, const float* scale, const float* shift, cons
 
 // out = [swish]( u * sigmoid(conv7x7(map, saw)) + xres ), u as above. map NULL -> att = 1.
 // att_out (B,H*W) optional (saved for backward). Replaces v2:79-81 and v2:176-177.
-int fl_res_tail_out(const float* y, const float* scale, const float* shift, const float* s, const float* map,
+int fl_res_tail_out(const float* y, const float* scale, const float* shift, const float* s, int s_per_image, const float* map,
                     const float* saw, const float* xres, float* out, float* att_out, int B, int H, int W, int C,
                     int final_swish, fl_stream_t stream) {
   FL_REQUIRE(y && out && C % 4 == 0, "fl_res_tail_out: bad args");
@@ -173,7 +173,7 @@ int fl_res_tail_out(const float* y, const float* scale, const float* shift, cons
   const long long npix = (long long)B * H * W;
   if (npix == 0) return FL_OK;
   const int C4 = C / 4;
-#define LAUNCH_OUT(L) hipLaunchKernelGGL(res_tail_out_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, saw, xres, out, att_out, B, H, W, C, final_swish)
+#define LAUNCH_OUT(L) hipLaunchKernelGGL(res_tail_out_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, saw, xres, out, att_out, B, H, W, C, final_swish, s_per_image)
   if (C4 >= 64) LAUNCH_OUT(64);
   else if (C4 >= 32) LAUNCH_OUT(32);
   else if (C4 >= 16) LAUNCH_OUT(16);

@@ -225,6 +225,25 @@ __global__ void advance_offset_kernel(long long* dev_offset, long long delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) dev_offset[0] += delta;
 }
 
+// out = a + sigmoid(w[0]) * b   (learned residual gate, v2:561), w on the device
+__global__ void gated_add_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ w,
+                                 float* __restrict__ out, long long n) {
+  const float s = fl::sigmoid_acc(w[0]);
+  GRID_STRIDE(i, n) out[i] = (a ? a[i] : 0.f) + s * b[i];
+}
+// out[0] = s(1-s) * sum x*y, s = sigmoid(w[0])  (gradient of the gate); single block
+__global__ void gate_grad_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ w,
+                                 float* __restrict__ out, long long n) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) a += x[i] * y[i];
+  a = fl::block_sum(a, red);
+  if (threadIdx.x == 0) {
+    const float s = fl::sigmoid_acc(w[0]);
+    out[0] = s * (1.f - s) * a;
+  }
+}
+
 // column sums: out[n] = sum_m x[m][n]  (bias gradients) — two-stage deterministic
 __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int M, int N, long long ldx,
                                       int rows_per_slab) {
@@ -238,12 +257,12 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __rest
   partial[(long long)blockIdx.y * N + c] = a;
 }
 __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int slabs, int N,
-                                    float beta) {
+                                    float alpha, float beta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= N) return;
   float a = 0.f;
   for (int s = 0; s < slabs; ++s) a += partial[(long long)s * N + c];
-  out[c] = beta != 0.f ? beta * out[c] + a : a;
+  out[c] = beta != 0.f ? beta * out[c] + alpha * a : alpha * a;
 }
 
 }  // namespace
@@ -355,14 +374,23 @@ int fl_advance_offset(int64_t* dev_offset, int64_t delta, fl_stream_t stream) {
   return fl::check_launch("advance_offset");
 }
 size_t fl_colsum_workspace_bytes(int M, int N) { return (size_t)fl::cdiv(M, 32) * N * sizeof(float); }
-int fl_colsum(const float* x, int64_t ldx, float* out, int M, int N, float beta, void* ws, size_t ws_bytes,
+int fl_gated_add(const float* a, const float* b, const float* w, float* out, int64_t n, fl_stream_t stream) {
+  if (!n) return FL_OK;
+  hipLaunchKernelGGL(gated_add_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), a, b, w, out, (long long)n);
+  return fl::check_launch("gated_add");
+}
+int fl_gate_grad(const float* x, const float* y, const float* w, float* out, int64_t n, fl_stream_t stream) {
+  hipLaunchKernelGGL(gate_grad_kernel, dim3(1), dim3(1024), 0, ST(stream), x, y, w, out, (long long)n);
+  return fl::check_launch("gate_grad");
+}
+int fl_colsum(const float* x, int64_t ldx, float* out, int M, int N, float alpha, float beta, void* ws, size_t ws_bytes,
               fl_stream_t stream) {
   FL_REQUIRE(ws && ws_bytes >= fl_colsum_workspace_bytes(M, N), "fl_colsum: workspace too small");
   if (!N) return FL_OK;
   const int rps = 32, slabs = fl::cdiv(M, rps);
   float* partial = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(fl::cdiv(N, 128), slabs > 0 ? slabs : 1), dim3(128), 0, ST(stream), x, partial, M, N, (long long)ldx, rps);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(fl::cdiv(N, 128)), dim3(128), 0, ST(stream), partial, out, slabs, N, beta);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(fl::cdiv(N, 128)), dim3(128), 0, ST(stream), partial, out, slabs, N, alpha, beta);
   return fl::check_launch("colsum");
 }
 

@@ -335,8 +335,8 @@ static int run_partial(int mode, const float* x, const float* dy, const float* s
 // ---- row LayerNorm (nn.LayerNorm over the last dim) ------------------------------
 // y = act(mask * (xhat*w + b)); one 256-thread block per row, three passes over an L2-hot row.
 __global__ void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                     const float* __restrict__ mask, float* __restrict__ y, float* __restrict__ mean,
-                                     float* __restrict__ rstd, int D, float eps, int act, float ap) {
+                                     const float* __restrict__ mask, const float* __restrict__ R, float* __restrict__ y,
+                                     float* __restrict__ mean, float* __restrict__ rstd, int D, float eps, int act, float ap) {
   __shared__ float red[8];
   const long long row = blockIdx.x;
   const float* xr = x + row * D;
@@ -376,6 +376,10 @@ __global__ void layernorm_fwd_kernel(const float* __restrict__ x, const float* _
     o.y = fl::apply_act(o.y, act, ap);
     o.z = fl::apply_act(o.z, act, ap);
     o.w = fl::apply_act(o.w, act, ap);
+    if (R) {
+      const float4 rr = ld4(R + row * D + i * 4);
+      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+    }
     st4(yr + i * 4, o);
   }
 }
@@ -384,7 +388,8 @@ __global__ void layernorm_fwd_kernel(const float* __restrict__ x, const float* _
 __global__ void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                         const float* __restrict__ w, const float* __restrict__ b,
                                         const float* __restrict__ mask, const float* __restrict__ mean,
-                                        const float* __restrict__ rstd, float* __restrict__ dx, int D, int act, float ap) {
+                                        const float* __restrict__ rstd, const float* __restrict__ R,
+                                        float* __restrict__ dx, int D, int act, float ap) {
   __shared__ float red[8];
   const long long row = blockIdx.x;
   const float m = mean[row], r = rstd[row];
@@ -409,7 +414,7 @@ __global__ void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const floa
     const float mk = mr ? mr[i] : 1.f;
     const float u = mk * (xh * w[i] + b[i]);
     const float gl = dr[i] * act_grad(u, act, ap) * mk;
-    dxr[i] = r * (gl * w[i] - t1 - xh * t2);
+    dxr[i] = r * (gl * w[i] - t1 - xh * t2) + (R ? R[row * D + i] : 0.f);
   }
 }
 
@@ -542,11 +547,11 @@ int fl_batchnorm_bwd(const float* dy, const float* x, const float* scale, const 
   return fl::check_launch("fl_batchnorm_bwd");
 }
 
-int fl_layernorm_fwd(const float* x, const float* w, const float* b, const float* mask, float* y, float* mean,
-                     float* rstd, int rows, int D, float eps, int act, float act_param, fl_stream_t stream) {
+int fl_layernorm_fwd(const float* x, const float* w, const float* b, const float* mask, const float* R, float* y,
+                     float* mean, float* rstd, int rows, int D, float eps, int act, float act_param, fl_stream_t stream) {
   FL_REQUIRE(x && w && b && y && D % 4 == 0, "fl_layernorm_fwd: bad args (D=%d)", D);
   if (rows == 0) return FL_OK;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, b, mask, y, mean, rstd, D, eps, act, act_param);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, b, mask, R, y, mean, rstd, D, eps, act, act_param);
   return fl::check_launch("layernorm_fwd_kernel");
 }
 
@@ -556,12 +561,12 @@ size_t fl_layernorm_bwd_workspace_bytes(int rows, int D) {
 }
 
 int fl_layernorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* mask,
-                     const float* mean, const float* rstd, float* dx, float* dw, float* db, int rows, int D, int act,
-                     float act_param, void* ws, size_t ws_bytes, fl_stream_t stream) {
+                     const float* mean, const float* rstd, const float* R, float* dx, float* dw, float* db, int rows, int D,
+                     int act, float act_param, void* ws, size_t ws_bytes, fl_stream_t stream) {
   FL_REQUIRE(dy && x && w && b && mean && rstd && dx, "fl_layernorm_bwd: null arg");
   if (rows == 0) return FL_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3(rows), dim3(256), 0, st, dy, x, w, b, mask, mean, rstd, dx, D, act, act_param);
+  hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3(rows), dim3(256), 0, st, dy, x, w, b, mask, mean, rstd, R, dx, D, act, act_param);
   if (dw || db) {
     FL_REQUIRE(ws && ws_bytes >= fl_layernorm_bwd_workspace_bytes(rows, D), "fl_layernorm_bwd: workspace too small");
     const int rps = 16, slabs = fl::cdiv(rows, rps);

@@ -1,0 +1,300 @@
+"""Functional forward/backward compositions of the v2 module surface over the C-ABI ops.
+
+Everything here works on NHWC fp32 device tensors and on the *parameter containers* of
+modules.py (real nn.Conv2d / nn.Linear / ... objects whose .weight/.bias carry the reference's
+state-dict keys); no torch arithmetic is executed — only libflowers_hip.so kernels.
+"""
+import torch
+
+from . import ops
+
+SW = ops.ACT_SWISH
+
+
+class PackCache:
+    """Derived weight layouts (packed conv weights), keyed by parameter version; never saved."""
+
+    def __init__(self):
+        self._c = {}
+        self.epoch = 0  # bumped by optimizers that update parameters through raw pointers
+
+    def get(self, key, params, fn):
+        ver = tuple((p._version, p.data_ptr()) for p in params) + (self.epoch,)
+        ent = self._c.get(key)
+        if ent is None or ent[0] != ver:
+            with torch.no_grad():
+                ent = (ver, fn())
+            self._c[key] = ent
+        return ent[1]
+
+    def conv(self, conv):
+        """nn.Conv2d (O,I,kh,kw) -> [O][kh][kw][Ipad]; nn.ConvTranspose2d (I,O,4,4) -> [I][4][4][O]."""
+        w = conv.weight
+        ipad = (w.shape[1] + 3) // 4 * 4
+        return self.get(("conv", id(conv)), [w], lambda: ops.pack_conv_weight(w.detach(), ipad))
+
+
+def _d(p):
+    return p.detach() if p is not None else None
+
+
+# ----------------------------------------------------------------------------- VAE blocks (inference)
+def ca_gate(ca, pooled):
+    """CALayer MLP (v2:57-62) on pooled (R,C) -> sigmoid gate (R,C)."""
+    w1 = _d(ca.conv_du[0].weight).view(ca.conv_du[0].weight.shape[0], -1)
+    w2 = _d(ca.conv_du[2].weight).view(ca.conv_du[2].weight.shape[0], -1)
+    h = ops.linear(pooled, w1, None, act=SW)
+    return ops.linear(h, w2, None, act=ops.ACT_SIGMOID)
+
+
+def resblock_infer(x, rb, pk):
+    """ResidualBlock.forward (v2:170-178), NHWC, no saved state. 2 convs + 2 stats passes + 3 streaming passes."""
+    y1 = ops.conv2d_fwd(x, pk.conv(rb.conv1), _d(rb.conv1.bias), 1, 1)
+    sc, sh, _, _ = ops.instnorm_stats(y1, _d(rb.ln1.weight), _d(rb.ln1.bias), rb.ln1.eps)
+    a1 = ops.affine_act(y1, sc, sh, act=SW, out=y1)
+    y2 = ops.conv2d_fwd(a1, pk.conv(rb.conv2), _d(rb.conv2.bias), 1, 1)
+    sc2, sh2, _, _ = ops.instnorm_stats(y2, _d(rb.ln2.weight), _d(rb.ln2.bias), rb.ln2.eps)
+    # avg_pool(LayerNorm2d(y)) == ln2.bias exactly (normalised maps have zero spatial mean), so the
+    # channel-attention gate (v2:65-66) is one (C,) vector shared by the batch: no pooling pass.
+    s = ca_gate(rb.ca, _d(rb.ln2.bias).view(1, -1)).view(-1)
+    m = ops.res_tail_map(y2, sc2, sh2, s)
+    return ops.res_tail_out(y2, sc2, sh2, s, m, _d(rb.sa.conv.weight).contiguous(), xres=x, final_swish=True)
+
+
+def _head(fc, flat):
+    """Linear -> LayerNorm -> Swish -> Linear (v2:210-221)."""
+    g = ops.linear(flat, _d(fc[0].weight), _d(fc[0].bias))
+    g, _, _ = ops.layernorm_fwd(g, _d(fc[1].weight), _d(fc[1].bias), eps=fc[1].eps, act=SW, save=False)
+    return ops.linear(g, _d(fc[3].weight), _d(fc[3].bias))
+
+
+def encoder_infer(enc, x):
+    """Encoder.forward (v2:223-239). x (B,3,64,64) NCHW -> mu, logvar (B,latent), [NHWC skip features]."""
+    pk = enc._pk
+    B = x.shape[0]
+    h = ops.nchw_to_nhwc(x, 4)
+    c0, ln0 = enc.initial_conv[0], enc.initial_conv[1]
+    y = ops.conv2d_fwd(h, pk.conv(c0), _d(c0.bias), 1, 1)
+    sc, sh, _, _ = ops.instnorm_stats(y, _d(ln0.weight), _d(ln0.bias), ln0.eps)
+    h = ops.affine_act(y, sc, sh, act=SW, out=y)
+    feats = [h]
+    for i in (1, 2, 3):
+        dn, rb = getattr(enc, "down%d" % i), getattr(enc, "res%d" % i)
+        y = ops.conv2d_fwd(h, pk.conv(dn[0]), _d(dn[0].bias), 2, 1)
+        sc, sh, _, _ = ops.instnorm_stats(y, _d(dn[1].weight), _d(dn[1].bias), dn[1].eps)
+        h = ops.affine_act(y, sc, sh, act=SW, out=y)
+        h = resblock_infer(h, rb, pk)
+        feats.append(h)
+    flat = ops.nhwc_to_nchw(h).view(B, -1)  # x.view(B,-1) of the NCHW tensor (v2:236)
+    return _head(enc.fc_mu, flat), _head(enc.fc_logvar, flat), feats
+
+
+def decoder_infer(dec, z):
+    """Decoder.forward (v2:280-290). z (B,latent) -> (B,3,64,64) NCHW in [0,1]."""
+    pk = dec._pk
+    B = z.shape[0]
+    fc = dec.fc
+    h = ops.linear(z, _d(fc[0].weight), _d(fc[0].bias))
+    h, _, _ = ops.layernorm_fwd(h, _d(fc[1].weight), _d(fc[1].bias), eps=fc[1].eps, act=SW, save=False)
+    h = ops.linear(h, _d(fc[3].weight), _d(fc[3].bias))
+    h, _, _ = ops.layernorm_fwd(h, _d(fc[4].weight), _d(fc[4].bias), eps=fc[4].eps, act=SW, save=False)
+    h = ops.nchw_to_nhwc(h.view(B, 512, 8, 8))  # view(-1,512,8,8) (v2:282) -> NHWC
+    for i in (3, 2, 1):
+        rb, up = getattr(dec, "res%d" % i), getattr(dec, "up%d" % i)
+        h = resblock_infer(h, rb, pk)
+        y = ops.convT2d_fwd(h, pk.conv(up[0]), _d(up[0].bias))
+        sc, sh, _, _ = ops.groupnorm_stats(y, _d(up[1].weight), _d(up[1].bias), up[1].num_groups, up[1].eps)
+        h = ops.affine_act(y, sc, sh, act=SW, out=y)
+    f = dec.final_conv
+    y = ops.conv2d_fwd(h, pk.conv(f[0]), _d(f[0].bias), 1, 1)
+    sc, sh, _, _ = ops.groupnorm_stats(y, _d(f[1].weight), _d(f[1].bias), f[1].num_groups, f[1].eps)
+    h = ops.affine_act(y, sc, sh, act=SW, out=y)
+    return ops.conv2d_fwd(h, pk.conv(f[3]), _d(f[3].bias), 1, 1, act=ops.ACT_SIGMOID, out_nchw=True)
+
+
+# ----------------------------------------------------------------------------- denoiser (v2:501-561)
+class UNetSaved:
+    __slots__ = ("x", "t", "c", "feat", "te1", "te1a", "te", "emb", "ce1", "ce1a", "ce", "tc", "layers", "hpre", "mean_f",
+                 "rstd_f", "hf", "r", "shared_t", "block_masks", "head_masks")
+
+
+def unet_forward(un, x, t, c, block_masks=None, head_masks=None, save=False):
+    """ConditionalUNet.forward. x (B,latent); t (B,) or (1,) int64; c (B,) int64 or None.
+    block_masks[i] (B,d_i) / head_masks[i] (B,heads) are dropout scale tensors (None = eval).
+    nn.MultiheadAttention on the length-1 sequence of v2:550 is out_proj(v_proj(.))."""
+    B = x.shape[0]
+    S = UNetSaved() if save else None
+    te_m, ce_m = un.time_emb, un.class_emb
+    feat = ops.time_sinusoid(t, un._freqs(x.device))
+    if save:
+        te1 = ops.linear(feat, _d(te_m.lin1.weight), _d(te_m.lin1.bias))
+        te1a = ops.act_fwd(te1, SW)
+    else:
+        te1, te1a = None, ops.linear(feat, _d(te_m.lin1.weight), _d(te_m.lin1.bias), act=SW)
+    te = ops.linear(te1a, _d(te_m.lin2.weight), _d(te_m.lin2.bias))
+    shared_t = te.shape[0] == 1 and B != 1
+    emb = ce1 = ce1a = ce = None
+    if c is not None:
+        emb = ops.embedding_fwd(_d(ce_m.embedding.weight), c)
+        if save:
+            ce1 = ops.linear(emb, _d(ce_m.lin1.weight), _d(ce_m.lin1.bias))
+            ce1a = ops.act_fwd(ce1, SW)
+        else:
+            ce1a = ops.linear(emb, _d(ce_m.lin1.weight), _d(ce_m.lin1.bias), act=SW)
+        ce = ops.linear(ce1a, _d(ce_m.lin2.weight), _d(ce_m.lin2.bias))
+        # W(te)+b + W(ce)+b == W(te+ce) + 2b: the class embedding goes through the *time* projection (v2:544)
+        tc = ops.add_rows(ce, te) if shared_t else ops.axpby(1.0, te, 1.0, ce)
+        tb = 2.0
+    else:
+        tc, tb = te, 1.0
+    h = ops.linear(x, _d(un.latent_proj.weight), _d(un.latent_proj.bias))
+    layers = []
+    for i, (block, norm, down) in enumerate(un.layers):
+        tp = un.time_projections[i]
+        if tc.shape[0] == B:
+            h1 = ops.linear(tc, _d(tp.weight), _d(tp.bias), bias_scale=tb, R=h)
+        else:  # one shared row (sampling without class conditioning)
+            h1 = ops.add_rows(h, ops.linear(tc, _d(tp.weight), _d(tp.bias), bias_scale=tb))
+        d = h1.shape[1]
+        lin, ln = block[0], block[1]
+        g = ops.linear(h1, _d(lin.weight), _d(lin.bias))
+        bm = block_masks[i] if block_masks is not None else None
+        h2, mg, rg = ops.layernorm_fwd(g, _d(ln.weight), _d(ln.bias), mask=bm, eps=ln.eps, act=SW, save=save, R=h1)
+        hn, mn, rn = ops.layernorm_fwd(h2, _d(norm.weight), _d(norm.bias), eps=norm.eps, save=save)
+        att = un.attention_layers[i]
+        wv, bv = _d(att.in_proj_weight)[2 * d:], _d(att.in_proj_bias)[2 * d:]
+        v = ops.linear(hn, wv, bv)
+        vm = ops.scale_heads(v, head_masks[i], att.num_heads) if head_masks is not None else v
+        h3 = ops.linear(vm, _d(att.out_proj.weight), _d(att.out_proj.bias), R=h2)
+        h = ops.linear(h3, _d(down.weight), _d(down.bias))
+        if save:
+            layers.append((h1, g, mg, rg, h2, mn, rn, hn, vm, h3))
+    ft, fcp = un.final_time_proj, un.final_class_proj
+    if shared_t:
+        h = ops.add_rows(h, ops.linear(te, _d(ft.weight), _d(ft.bias)))
+    else:
+        h = ops.linear(te, _d(ft.weight), _d(ft.bias), R=h)
+    if ce is not None:
+        h = ops.linear(ce, _d(fcp.weight), _d(fcp.bias), R=h)
+    hf, mf, rf = ops.layernorm_fwd(h, _d(un.final_norm.weight), _d(un.final_norm.bias), eps=un.final_norm.eps, save=save)
+    r = ops.linear(x, _d(un.final.weight), _d(un.final.bias))
+    o1 = ops.linear(hf, _d(un.final.weight), _d(un.final.bias))
+    out = ops.gated_add(o1, r, _d(un.residual_weight).view(1))  # out + sigmoid(residual_weight)*final(x) (v2:561)
+    if save:
+        S.x, S.t, S.c, S.feat, S.te1, S.te1a, S.te = x, t, c, feat, te1, te1a, te
+        S.emb, S.ce1, S.ce1a, S.ce, S.tc, S.layers = emb, ce1, ce1a, ce, tc, layers
+        S.hpre, S.mean_f, S.rstd_f, S.hf, S.r, S.shared_t = h, mf, rf, hf, r, shared_t
+        S.block_masks, S.head_masks = block_masks, head_masks
+    return out, S
+
+
+def unet_backward(un, S, dout, need_dx=False, gout=None):
+    """Manual backward of unet_forward. Returns ({parameter name: grad tensor}, dx or None).
+    `gout` {name: preallocated grad tensor} lets the trainer receive gradients directly in its flat buffer.
+    Parameters the forward never touches (time_projections.4, attention_layers.4) get no gradient and the q/k
+    rows of in_proj get exactly zero, like autograd on the reference."""
+    if S.shared_t:
+        raise RuntimeError("backward with a shared (1,) time row is not supported (training uses per-sample t)")
+    G = {}
+
+    def go(name):
+        return gout.get(name) if gout is not None else None
+
+    def wgrad(name, dy, x):
+        G[name] = ops.linear_wgrad(dy, x, out=go(name))
+
+    def bgrad(name, dy, alpha=1.0):
+        G[name] = ops.colsum(dy, out=go(name), alpha=alpha)
+
+    rw = _d(un.residual_weight).view(1)
+    Wf = _d(un.final.weight)
+    # out = final(hf) + sig*final(x): one weight, two uses
+    u = ops.gated_add(S.hf, S.x, rw)                      # hf + sig*x
+    wgrad("final.weight", dout, u)
+    cs = ops.colsum(dout)
+    G["final.bias"] = ops.gated_add(cs, cs, rw, out=go("final.bias"))   # (1+sig) * colsum
+    grw = go("residual_weight")
+    G["residual_weight"] = ops.gate_grad(dout, S.r, rw, out=grw.view(1) if grw is not None else None).view(())
+    dhf = ops.linear_dgrad(dout, Wf)                      # also the x-branch gradient / sig
+    fn = un.final_norm
+    dh, G["final_norm.weight"], G["final_norm.bias"] = ops.layernorm_bwd(
+        dhf, S.hpre, _d(fn.weight), _d(fn.bias), None, S.mean_f, S.rstd_f, dw_out=go("final_norm.weight"),
+        db_out=go("final_norm.bias"))
+    dce = None
+    wgrad("final_time_proj.weight", dh, S.te)
+    bgrad("final_time_proj.bias", dh)
+    dte = ops.linear_dgrad(dh, _d(un.final_time_proj.weight))
+    if S.ce is not None:
+        wgrad("final_class_proj.weight", dh, S.ce)
+        bgrad("final_class_proj.bias", dh)
+        dce = ops.linear_dgrad(dh, _d(un.final_class_proj.weight))
+    dtc = None
+    tb = 2.0 if S.ce is not None else 1.0
+    for i in reversed(range(len(un.layers))):
+        block, norm, down = un.layers[i]
+        h1, g, mg, rg, h2, mn, rn, hn, vm, h3 = S.layers[i]
+        d = h1.shape[1]
+        pre = "layers.%d." % i
+        wgrad(pre + "2.weight", dh, h3)
+        bgrad(pre + "2.bias", dh)
+        dh3 = ops.linear_dgrad(dh, _d(down.weight))
+        att = un.attention_layers[i]
+        ap = "attention_layers.%d." % i
+        wgrad(ap + "out_proj.weight", dh3, vm)
+        bgrad(ap + "out_proj.bias", dh3)
+        dv = ops.linear_dgrad(dh3, _d(att.out_proj.weight))
+        if S.head_masks is not None:
+            dv = ops.scale_heads(dv, S.head_masks[i], att.num_heads)
+        # q/k rows: exactly zero gradient (softmax over one key); preallocated buffers are zero there already
+        gw = go(ap + "in_proj_weight")
+        gb = go(ap + "in_proj_bias")
+        if gw is None:
+            gw = torch.zeros_like(att.in_proj_weight)
+            gb = torch.zeros_like(att.in_proj_bias)
+        ops.linear_wgrad(dv, hn, out=gw[2 * d:])
+        ops.colsum(dv, out=gb[2 * d:])
+        G[ap + "in_proj_weight"], G[ap + "in_proj_bias"] = gw, gb
+        dhn = ops.linear_dgrad(dv, _d(att.in_proj_weight)[2 * d:])
+        dh2, G[pre + "1.weight"], G[pre + "1.bias"] = ops.layernorm_bwd(
+            dhn, h2, _d(norm.weight), _d(norm.bias), None, mn, rn, R=dh3, dw_out=go(pre + "1.weight"),
+            db_out=go(pre + "1.bias"))
+        lin, ln = block[0], block[1]
+        bm = S.block_masks[i] if S.block_masks is not None else None
+        dg, G[pre + "0.1.weight"], G[pre + "0.1.bias"] = ops.layernorm_bwd(
+            dh2, g, _d(ln.weight), _d(ln.bias), bm, mg, rg, act=SW, dw_out=go(pre + "0.1.weight"),
+            db_out=go(pre + "0.1.bias"))
+        wgrad(pre + "0.0.weight", dg, h1)
+        bgrad(pre + "0.0.bias", dg)
+        dh1 = ops.gemm(dg, _d(lin.weight), dg.shape[0], d, d, a_layout=ops.KC, b_layout=ops.KS, lda=d, ldb=d, R=dh2)
+        tp = un.time_projections[i]
+        tpp = "time_projections.%d." % i
+        wgrad(tpp + "weight", dh1, S.tc)
+        bgrad(tpp + "bias", dh1, alpha=tb)
+        K = tp.weight.shape[1]
+        dtc = ops.gemm(dh1, _d(tp.weight), dh1.shape[0], K, d, a_layout=ops.KC, b_layout=ops.KS, lda=d, ldb=K, R=dtc)
+        dh = dh1
+    wgrad("latent_proj.weight", dh, S.x)
+    bgrad("latent_proj.bias", dh)
+    dx = None
+    if need_dx:
+        dx = ops.gated_add(ops.linear_dgrad(dh, _d(un.latent_proj.weight)), dhf, rw)
+    # time / class embedding MLPs
+    dte = ops.axpby(1.0, dte, 1.0, dtc)
+    tm = un.time_emb
+    wgrad("time_emb.lin2.weight", dte, S.te1a)
+    bgrad("time_emb.lin2.bias", dte)
+    d1 = ops.act_bwd(ops.linear_dgrad(dte, _d(tm.lin2.weight)), S.te1, SW)
+    wgrad("time_emb.lin1.weight", d1, S.feat)
+    bgrad("time_emb.lin1.bias", d1)
+    if S.ce is not None:
+        dce = ops.axpby(1.0, dce, 1.0, dtc)
+        cm = un.class_emb
+        wgrad("class_emb.lin2.weight", dce, S.ce1a)
+        bgrad("class_emb.lin2.bias", dce)
+        d1 = ops.act_bwd(ops.linear_dgrad(dce, _d(cm.lin2.weight)), S.ce1, SW)
+        wgrad("class_emb.lin1.weight", d1, S.emb)
+        bgrad("class_emb.lin1.bias", d1)
+        demb = ops.linear_dgrad(d1, _d(cm.lin1.weight))
+        G["class_emb.embedding.weight"] = ops.embedding_bwd(demb, S.c, cm.embedding.weight.shape[0],
+                                                            out=go("class_emb.embedding.weight"))
+    return G, dx

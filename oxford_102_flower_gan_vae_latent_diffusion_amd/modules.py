@@ -1,0 +1,570 @@
+"""Drop-in nn.Module surface of v2/model_train_test.py on the MI355X engine.
+
+Constructor signatures, attribute names, method names and state-dict keys/shapes are the
+reference's, so reference checkpoints load with load_state_dict and the
+reference train/visualise loops run unchanged. The sub-modules (nn.Conv2d, nn.Linear,
+nn.LayerNorm, ...) are *parameter containers*: their forward is never called — forward and
+backward run hand-written HIP kernels through engine.py / ops.py. Module I/O is NCHW like the
+reference; internally activations are NHWC.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import engine, ops
+from .rng import Philox
+
+
+def _need_grad(*tensors_or_modules):
+    if not torch.is_grad_enabled():
+        return False
+    for o in tensors_or_modules:
+        if isinstance(o, torch.Tensor):
+            if o.requires_grad:
+                return True
+        elif o is not None:
+            if any(p.requires_grad for p in o.parameters()):
+                return True
+    return False
+
+
+def _f32c(x):
+    if x.dtype != torch.float32:
+        raise TypeError("flowers engine is fp32 (got %s)" % x.dtype)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+# ----------------------------------------------------------------------------- primitives
+class _SwishFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        ctx.save_for_backward(x)
+        return ops.act_fwd(x, ops.ACT_SWISH)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.act_bwd(_f32c(dy), x, ops.ACT_SWISH)
+
+
+class Swish(nn.Module):
+    """v2:48-50."""
+
+    def forward(self, x):
+        return _SwishFn.apply(x)
+
+
+class LayerNorm2d(nn.Module):
+    """v2:144-156 (instance statistics over H,W; per-channel affine)."""
+
+    def __init__(self, num_channels, eps=1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+        self.eps = eps
+
+    def forward(self, x):
+        return _LayerNorm2dFn.apply(x, self.weight, self.bias, self.eps)
+
+
+class _LayerNorm2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        C = x.shape[1]
+        cp = (C + 3) // 4 * 4
+        if cp != C:
+            raise ValueError("LayerNorm2d: channels must be a multiple of 4 on this engine")
+        xh = ops.nchw_to_nhwc(_f32c(x))
+        sc, sh, mean, rstd = ops.instnorm_stats(xh, w.detach(), b.detach(), eps)
+        y = ops.affine_act(xh, sc, sh)
+        ctx.save_for_backward(xh, sc, sh, mean, rstd, w.detach())
+        return ops.nhwc_to_nchw(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, sc, sh, mean, rstd, w = ctx.saved_tensors
+        dx, dw, db = ops.instnorm_bwd(ops.nchw_to_nhwc(_f32c(dy)), xh, sc, sh, w, mean, rstd)
+        return ops.nhwc_to_nchw(dx), dw, db, None
+
+
+class CALayer(nn.Module):
+    """v2:53-67."""
+
+    def __init__(self, channel, reduction=8):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.conv_du = nn.Sequential(
+            nn.Conv2d(channel, channel // reduction, 1, padding=0, bias=False),
+            Swish(),
+            nn.Conv2d(channel // reduction, channel, 1, padding=0, bias=False),
+            nn.Sigmoid(),
+        )
+
+    def forward(self, x):
+        if _need_grad(x, self):
+            from . import engine_bwd
+            return engine_bwd.CALayerFn.apply(self, x, self.conv_du[0].weight, self.conv_du[2].weight)
+        xh = ops.nchw_to_nhwc(_f32c(x))
+        _, _, mean, _ = ops.instnorm_stats(xh, None, None)
+        s = engine.ca_gate(self, mean)
+        return ops.nhwc_to_nchw(ops.res_tail_out(xh, None, None, s))
+
+
+class SpatialAttention(nn.Module):
+    """v2:69-81."""
+
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        if kernel_size != 7:
+            raise ValueError("SpatialAttention: the engine implements the 7x7 kernel of v2:70")
+        self.conv = nn.Conv2d(2, 1, kernel_size=kernel_size, padding=kernel_size // 2, bias=False)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        if _need_grad(x, self):
+            from . import engine_bwd
+            return engine_bwd.SpatialAttentionFn.apply(self, x, self.conv.weight)
+        xh = ops.nchw_to_nhwc(_f32c(x))
+        m = ops.res_tail_map(xh)
+        return ops.nhwc_to_nchw(ops.res_tail_out(xh, None, None, None, m, self.conv.weight.detach().contiguous()))
+
+
+class ResidualBlock(nn.Module):
+    """v2:159-178."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(channels, channels, 3, padding=1)
+        self.ln1 = LayerNorm2d(channels)
+        self.swish = Swish()
+        self.conv2 = nn.Conv2d(channels, channels, 3, padding=1)
+        self.ln2 = LayerNorm2d(channels)
+        self.ca = CALayer(channels)
+        self.sa = SpatialAttention()
+        self._pk = engine.PackCache()
+
+    def forward(self, x):
+        if _need_grad(x, self):
+            from . import engine_bwd
+            return engine_bwd.ResidualBlockFn.apply(self, x, *engine_bwd.resblock_params(self))
+        xh = ops.nchw_to_nhwc(_f32c(x))
+        return ops.nhwc_to_nchw(engine.resblock_infer(xh, self, self._pk))
+
+
+# ----------------------------------------------------------------------------- VAE
+class Encoder(nn.Module):
+    """v2:181-239."""
+
+    def __init__(self, in_channels=3, latent_dim=256):
+        super().__init__()
+        if in_channels != 3:
+            raise ValueError("Encoder: the engine implements the 3-channel 64x64 path of v2")
+        self.latent_dim = latent_dim
+        self.initial_conv = nn.Sequential(nn.Conv2d(in_channels, 64, 3, padding=1), LayerNorm2d(64), Swish())
+        self.skip_features = []
+        self.down1 = nn.Sequential(nn.Conv2d(64, 128, 4, stride=2, padding=1), LayerNorm2d(128), Swish())
+        self.res1 = ResidualBlock(128)
+        self.down2 = nn.Sequential(nn.Conv2d(128, 256, 4, stride=2, padding=1), LayerNorm2d(256), Swish())
+        self.res2 = ResidualBlock(256)
+        self.down3 = nn.Sequential(nn.Conv2d(256, 512, 4, stride=2, padding=1), LayerNorm2d(512), Swish())
+        self.res3 = ResidualBlock(512)
+        self.fc_mu = nn.Sequential(nn.Linear(512 * 8 * 8, 512), nn.LayerNorm(512), Swish(), nn.Linear(512, latent_dim))
+        self.fc_logvar = nn.Sequential(nn.Linear(512 * 8 * 8, 512), nn.LayerNorm(512), Swish(), nn.Linear(512, latent_dim))
+        self._pk = engine.PackCache()
+
+    def forward(self, x):
+        if x.shape[1:] != (3, 64, 64):
+            # same failure mode as the reference, whose fc layers hard-code 512*8*8 inputs (v2:211)
+            raise RuntimeError("Encoder expects (B,3,64,64) inputs, got %s" % (tuple(x.shape),))
+        if _need_grad(x, self):
+            from . import engine_bwd
+            mu, logvar = engine_bwd.EncoderFn.apply(self, x, *engine_bwd.encoder_params(self))
+            return mu, logvar
+        mu, logvar, feats = engine.encoder_infer(self, _f32c(x))
+        self.skip_features = [f.permute(0, 3, 1, 2) for f in feats]  # NCHW views of the NHWC activations
+        return mu, logvar
+
+
+class Decoder(nn.Module):
+    """v2:242-290."""
+
+    def __init__(self, latent_dim=256, out_channels=3):
+        super().__init__()
+        if out_channels != 3:
+            raise ValueError("Decoder: the engine implements the 3-channel 64x64 path of v2")
+        self.latent_dim = latent_dim
+        self.fc = nn.Sequential(nn.Linear(latent_dim, 512), nn.LayerNorm(512), Swish(), nn.Linear(512, 512 * 8 * 8),
+                                nn.LayerNorm(512 * 8 * 8), Swish())
+        self.res3 = ResidualBlock(512)
+        self.up3 = nn.Sequential(nn.ConvTranspose2d(512, 256, 4, stride=2, padding=1), nn.GroupNorm(32, 256), Swish())
+        self.res2 = ResidualBlock(256)
+        self.up2 = nn.Sequential(nn.ConvTranspose2d(256, 128, 4, stride=2, padding=1), nn.GroupNorm(16, 128), Swish())
+        self.res1 = ResidualBlock(128)
+        self.up1 = nn.Sequential(nn.ConvTranspose2d(128, 64, 4, stride=2, padding=1), nn.GroupNorm(8, 64), Swish())
+        self.final_conv = nn.Sequential(nn.Conv2d(64, 32, 3, padding=1), nn.GroupNorm(8, 32), Swish(),
+                                        nn.Conv2d(32, out_channels, 3, padding=1), nn.Sigmoid())
+        self._pk = engine.PackCache()
+
+    def forward(self, z, encoder_features=None):  # encoder_features unused, as in v2:280
+        if _need_grad(z, self):
+            from . import engine_bwd
+            return engine_bwd.DecoderFn.apply(self, z, *engine_bwd.decoder_params(self))
+        return engine.decoder_infer(self, _f32c(z))
+
+
+def euclidean_distance_loss(x, y, reduction="mean"):
+    """v2:293-302: per-sample L2 norm, then mean / sum / none over the batch."""
+    red = {"mean": 1, "sum": 2}.get(reduction, 0)
+    return _EuclidFn.apply(x, y, red)
+
+
+class _EuclidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, red):
+        x, y = _f32c(x), _f32c(y)
+        loss, norms = ops.euclid_loss_fwd(x, y, red)
+        ctx.save_for_backward(x, y, norms)
+        ctx.red = red
+        return norms if red == 0 else loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, norms = ctx.saved_tensors
+        if ctx.red == 0:  # per-sample upstream gradients: fold them into the norms (dx = g_b (x-y)/n_b)
+            raise NotImplementedError("euclidean_distance_loss(reduction='none').backward is not used by the v2 loops")
+        gdev = _f32c(g).view(1)
+        need_y = ctx.needs_input_grad[1]
+        r = ops.euclid_loss_bwd(x, y, norms, 1.0, gdev, ctx.red, need_dy=need_y)
+        dx, dy = r if need_y else (r, None)
+        return (dx if ctx.needs_input_grad[0] else None), dy, None
+
+
+class SimpleAutoencoder(nn.Module):
+    """v2:305-393."""
+
+    def __init__(self, in_channels=3, latent_dim=256, num_classes=102):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.encoder = Encoder(in_channels, latent_dim)
+        self.decoder = Decoder(latent_dim, in_channels)
+        self.classifier = nn.Sequential(nn.Linear(latent_dim, 512), nn.LayerNorm(512), Swish(), nn.Dropout(0.3),
+                                        nn.Linear(512, 256), nn.LayerNorm(256), Swish(), nn.Dropout(0.2),
+                                        nn.Linear(256, num_classes))
+        self.register_buffer("class_centers", torch.zeros(num_classes, latent_dim))
+        self.register_buffer("center_counts", torch.zeros(num_classes))
+        self.rng = Philox(seed=42)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):  # v2:326-337
+        if isinstance(m, nn.Linear):
+            nn.init.kaiming_normal_(m.weight, a=0.2)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm2d)):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+        elif isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            nn.init.kaiming_normal_(m.weight, a=0.2)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+    def reparameterize(self, mu, logvar, eps=None):
+        """v2:339-343; `eps` may be supplied (explicit-noise parity runs), else Philox N(0,1)."""
+        if eps is None:
+            eps = self.rng.normal(mu.shape, mu.device)
+        return _ReparamFn.apply(mu, logvar, eps)
+
+    def encode(self, x):
+        mu, logvar = self.encoder(x)
+        return self.reparameterize(mu, logvar)
+
+    def encode_with_params(self, x):
+        mu, logvar = self.encoder(x)
+        return mu, _ClampLogvarFn.apply(logvar)
+
+    def decode(self, z):
+        return self.decoder(z, getattr(self, "stored_encoder_features", None))
+
+    def classify(self, z):
+        from . import engine_bwd
+        return engine_bwd.classify(self, z)
+
+    def compute_center_loss(self, z, labels):
+        """v2:362-367."""
+        centers_batch = ops.gather_rows(self.class_centers, labels)
+        return euclidean_distance_loss(z, centers_batch)
+
+    @torch.no_grad()
+    def update_centers(self, z, labels, momentum=0.9):
+        """v2:369-378 without the python loop / host syncs: one kernel over (classes x latent)."""
+        ops.update_centers(self.class_centers, _f32c(z.detach()), labels, momentum)
+
+    def kl_divergence(self, mu, logvar):
+        """v2:380-386."""
+        return _KLFn.apply(mu, logvar)
+
+    def forward(self, x, eps=None):
+        mu, logvar = self.encoder(x)
+        z = self.reparameterize(mu, logvar, eps)
+        self.stored_encoder_features = self.encoder.skip_features
+        x_recon = self.decoder(z, self.encoder.skip_features)
+        return x_recon, mu, logvar, z
+
+
+class _ReparamFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = _f32c(mu), _f32c(logvar), _f32c(eps)
+        z, _ = ops.reparameterize(mu, logvar, eps)
+        ctx.save_for_backward(logvar, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        from . import engine_bwd
+        logvar, eps = ctx.saved_tensors
+        return _f32c(dz), engine_bwd.reparam_dlogvar(_f32c(dz), logvar, eps), None
+
+
+class _ClampLogvarFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logvar):
+        logvar = _f32c(logvar)
+        _, lvc = ops.reparameterize(logvar, logvar, None, want_clamped=True)
+        ctx.save_for_backward(logvar)
+        return lvc
+
+    @staticmethod
+    def backward(ctx, d):
+        from . import engine_bwd
+        (logvar,) = ctx.saved_tensors
+        return engine_bwd.clamp_bwd(_f32c(d), logvar, -2.0, 10.0)
+
+
+class _KLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = _f32c(mu), _f32c(logvar)
+        loss, kl_row = ops.kl_fwd(mu, logvar)
+        ctx.save_for_backward(mu, logvar, kl_row)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar, kl_row = ctx.saved_tensors
+        return ops.kl_bwd(mu, logvar, kl_row, 1.0, _f32c(g).view(1))
+
+
+# ----------------------------------------------------------------------------- denoiser
+class TimeEmbedding(nn.Module):
+    """v2:401-418 (parameter container + stand-alone forward)."""
+
+    def __init__(self, n_channels=256):
+        super().__init__()
+        self.n_channels = n_channels
+        self.lin1 = nn.Linear(self.n_channels, self.n_channels * 2)
+        self.act = Swish()
+        self.lin2 = nn.Linear(self.n_channels * 2, self.n_channels)
+
+    def forward(self, t):
+        feat = ops.time_sinusoid(t, ops.time_freqs(self.n_channels, t.device))
+        h = ops.linear(feat, self.lin1.weight.detach(), self.lin1.bias.detach(), act=ops.ACT_SWISH)
+        return ops.linear(h, self.lin2.weight.detach(), self.lin2.bias.detach())
+
+
+class ClassEmbedding(nn.Module):
+    """v2:421-431."""
+
+    def __init__(self, num_classes=102, n_channels=256):
+        super().__init__()
+        self.embedding = nn.Embedding(num_classes, n_channels)
+        self.lin1 = nn.Linear(n_channels, n_channels)
+        self.act = Swish()
+        self.lin2 = nn.Linear(n_channels, n_channels)
+
+    def forward(self, c):
+        e = ops.embedding_fwd(self.embedding.weight.detach(), c)
+        h = ops.linear(e, self.lin1.weight.detach(), self.lin1.bias.detach(), act=ops.ACT_SWISH)
+        return ops.linear(h, self.lin2.weight.detach(), self.lin2.bias.detach())
+
+
+class ConditionalUNet(nn.Module):
+    """v2:501-561 — the live denoiser: an MLP over flat latents with length-1 'attention'."""
+
+    def __init__(self, latent_dim=256, hidden_dims=[256, 512, 1024, 512, 256], time_emb_dim=256, num_classes=102,
+                 dropout_rate=0.3):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.time_emb_dim = time_emb_dim
+        self.dropout_rate = dropout_rate
+        self.time_emb = TimeEmbedding(n_channels=time_emb_dim)
+        self.class_emb = ClassEmbedding(num_classes=num_classes, n_channels=time_emb_dim)
+        self.latent_proj = nn.Linear(latent_dim, hidden_dims[0])
+        self.time_projections = nn.ModuleList([nn.Linear(time_emb_dim, dim) for dim in hidden_dims])
+        self.attention_layers = nn.ModuleList(
+            [nn.MultiheadAttention(embed_dim=dim, num_heads=8, dropout=dropout_rate) for dim in hidden_dims])
+        self.layers = nn.ModuleList()
+        for i in range(len(hidden_dims) - 1):
+            residual_block = nn.Sequential(nn.Linear(hidden_dims[i], hidden_dims[i]), nn.LayerNorm(hidden_dims[i]),
+                                           nn.Dropout(dropout_rate), Swish())
+            layer_norm = nn.LayerNorm(hidden_dims[i])
+            proj = nn.Linear(hidden_dims[i], hidden_dims[i + 1])
+            self.layers.append(nn.ModuleList([residual_block, layer_norm, proj]))
+        self.final_time_proj = nn.Linear(time_emb_dim, hidden_dims[-1])
+        self.final_class_proj = nn.Linear(time_emb_dim, hidden_dims[-1])
+        self.final_norm = nn.LayerNorm(hidden_dims[-1])
+        self.final = nn.Linear(hidden_dims[-1], latent_dim)
+        self.residual_weight = nn.Parameter(torch.tensor(0.1))
+        self.rng = Philox(seed=44)
+        self._freq_cache = {}
+
+    def _freqs(self, device):
+        f = self._freq_cache.get(device)
+        if f is None:
+            f = ops.time_freqs(self.time_emb_dim, device)
+            self._freq_cache[device] = f
+        return f
+
+    def dropout_masks(self, B, device):
+        """Philox dropout-scale tensors for train mode: (block_masks, head_masks)."""
+        bm, hm = [], []
+        for i, (block, _, _) in enumerate(self.layers):
+            d = block[0].weight.shape[0]
+            bm.append(self.rng.dropout((B, d), device, block[2].p))
+            att = self.attention_layers[i]
+            hm.append(self.rng.dropout((B, att.num_heads), device, att.dropout))
+        return bm, hm
+
+    def forward(self, x, t, c=None, block_masks=None, head_masks=None):
+        x = _f32c(x)
+        if t.dtype != torch.int64:
+            t = t.long()
+        if c is not None and c.dtype != torch.int64:
+            c = c.long()
+        if self.training and block_masks is None and self.dropout_rate > 0:
+            block_masks, head_masks = self.dropout_masks(x.shape[0], x.device)
+        if _need_grad(x, self):
+            names = [n for n, _ in self.named_parameters()]
+            params = [p for _, p in self.named_parameters()]
+            return _UNetFn.apply(self, names, x, t, c, block_masks, head_masks, *params)
+        out, _ = engine.unet_forward(self, x, t, c, block_masks, head_masks, save=False)
+        return out
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, un, names, x, t, c, block_masks, head_masks, *params):
+        out, S = engine.unet_forward(un, x, t, c, block_masks, head_masks, save=True)
+        ctx.un, ctx.S, ctx.names = un, S, names
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        G, dx = engine.unet_backward(ctx.un, ctx.S, _f32c(dout), need_dx=ctx.needs_input_grad[2])
+        ctx.S = None
+        return (None, None, dx, None, None, None, None) + tuple(G.get(n) for n in ctx.names)
+
+
+class ConditionalDenoiseDiffusion:
+    """v2:564-607. `sample` is also reachable as `p_sample_loop` (name used by BASELINE.json)."""
+
+    def __init__(self, eps_model, n_steps=1000, device=None):
+        self.eps_model = eps_model
+        self.device = device
+        # schedule constants are computed on the host exactly like the reference's CPU path (v2:569-571)
+        beta = torch.linspace(0.0001, 0.02, n_steps)
+        alpha = 1 - beta
+        self.beta = beta.to(device)
+        self.alpha = alpha.to(device)
+        self.alpha_bar = torch.cumprod(alpha, dim=0).to(device)
+        self.n_steps = n_steps
+        self.rng = Philox(seed=1234)
+
+    def q_sample(self, x0, t, eps=None):
+        if eps is None:
+            eps = self.rng.normal(x0.shape, x0.device)
+        return ops.q_sample(_f32c(x0), _f32c(eps), t, self.alpha_bar)
+
+    def p_sample(self, xt, t, c=None, noise=None):
+        """v2:580-592. t: python int or (1,) tensor shared by the batch; the `t>0` test is done on the device."""
+        if not isinstance(t, torch.Tensor):
+            t = torch.tensor([t], device=xt.device)
+        t64 = t.long().reshape(-1)[:1].contiguous()
+        t32 = t64.to(torch.int32)
+        with torch.no_grad():
+            eps_theta = self.eps_model(xt, t64, c)
+            if noise is None:
+                noise = self.rng.normal(xt.shape, xt.device)
+            return ops.p_sample_update(_f32c(xt), eps_theta, _f32c(noise), t32, self.alpha, self.alpha_bar, self.beta)
+
+    def sample(self, shape, device, c=None, x_T=None, use_graph=True):
+        """v2:594-598: x_T ~ N(0,1), then n_steps reverse steps. One step (denoiser + update + Philox noise +
+        device-side step counter) is captured into a hipGraph and replayed n_steps times."""
+        from .sampler import GraphSampler
+        return GraphSampler(self, shape, device, c, use_graph=use_graph).run(x_T)
+
+    p_sample_loop = sample
+
+    def loss(self, x0, labels=None, t=None, eps=None):
+        """v2:600-607; t / eps may be supplied explicitly (parity), else drawn from Philox."""
+        B = x0.shape[0]
+        if t is None:
+            t = self.rng.randint((B,), x0.device, self.n_steps)
+        if eps is None:
+            eps = self.rng.normal(x0.shape, x0.device)
+        xt = self.q_sample(x0.detach(), t, eps)
+        eps_theta = self.eps_model(xt, t, labels)
+        return euclidean_distance_loss(eps, eps_theta)
+
+
+# ----------------------------------------------------------------------------- perceptual / GAN
+class VGGPerceptualLoss(nn.Module):
+    """v2:962-981. torchvision's pretrained VGG16 cannot be downloaded here: `feature_extractor` has the
+    features[:16] layout (conv indices 0,2,5,7,10,12,14) so a user's local torchvision state-dict loads by key;
+    without one the weights are seeded-synthetic (kaiming), good for throughput/parity runs."""
+
+    CFG = [(0, 3, 64), (2, 64, 64), "M", (5, 64, 128), (7, 128, 128), "M", (10, 128, 256), (12, 256, 256), (14, 256, 256)]
+
+    def __init__(self, device, state_dict=None):
+        super().__init__()
+        layers = []
+        for item in [64, 64, "M", 128, 128, "M", 256, 256, 256]:
+            if item == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                cin = 3 if not layers else [l for l in layers if isinstance(l, nn.Conv2d)][-1].out_channels
+                layers += [nn.Conv2d(cin, item, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+        vgg = nn.Sequential(*layers[:16]).to(device)
+        if state_dict is not None:
+            vgg.load_state_dict(state_dict)
+        for param in vgg.parameters():
+            param.requires_grad = False
+        self.feature_extractor = vgg
+        self.criterion = euclidean_distance_loss
+        self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1).to(device))
+        self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1).to(device))
+        self._pk = engine.PackCache()
+
+    def forward(self, x, y):
+        from . import engine_bwd
+        return engine_bwd.vgg_loss(self, x, y)
+
+
+class Discriminator64(nn.Module):
+    """v2:983-1007."""
+
+    def __init__(self, in_channels=3):
+        super().__init__()
+        self.model = nn.Sequential(
+            nn.Conv2d(in_channels, 64, 4, stride=2, padding=1), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(64, 128, 4, stride=2, padding=1), nn.BatchNorm2d(128), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(128, 256, 4, stride=2, padding=1), nn.BatchNorm2d(256), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(256, 512, 4, stride=2, padding=1), nn.BatchNorm2d(512), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(512, 1, 4), nn.Sigmoid())
+        self._pk = engine.PackCache()
+
+    def forward(self, x):
+        from . import engine_bwd
+        return engine_bwd.discriminator(self, x)

@@ -101,13 +101,30 @@ def linear_wgrad(dy, x, out=None):
     return gemm(dy, x, N, K, M, a_layout=KS, b_layout=KS, lda=N, ldb=K, out=out)
 
 
-def colsum(x, out=None, beta=0.0):
+def colsum(x, out=None, alpha=1.0, beta=0.0):
     M, N = x.shape
     _chk(x, out)
     if out is None:
         out = new((N,), x)
     wsp, wsn = _ws(_lib.load().fl_colsum_workspace_bytes(M, N), x)
-    _lib.call("fl_colsum", _p(x), N, _p(out), M, N, float(beta), wsp, wsn, _stream())
+    _lib.call("fl_colsum", _p(x), N, _p(out), M, N, float(alpha), float(beta), wsp, wsn, _stream())
+    return out
+
+
+def gated_add(a, b, w, out=None):
+    """out = a + sigmoid(w[0]) * b (a may be None)."""
+    _chk(a, b, w, out)
+    if out is None:
+        out = torch.empty_like(b)
+    _lib.call("fl_gated_add", _p(a), _p(b), _p(w), _p(out), b.numel(), _stream())
+    return out
+
+
+def gate_grad(x, y, w, out=None):
+    _chk(x, y, w, out)
+    if out is None:
+        out = new((1,), x)
+    _lib.call("fl_gate_grad", _p(x), _p(y), _p(w), _p(out), x.numel(), _stream())
     return out
 
 
@@ -268,25 +285,26 @@ def batchnorm_bwd(dy, x, scale, shift, w, mean, rstd, act=ACT_NONE, act_param=0.
     return dx, dw, db
 
 
-def layernorm_fwd(x, w, b, mask=None, eps=1e-5, act=ACT_NONE, act_param=0.0, save=True):
-    """Row LayerNorm: y = act(mask*(xhat*w+b)). -> y, mean, rstd."""
-    _chk(x, w, b, mask)
+def layernorm_fwd(x, w, b, mask=None, eps=1e-5, act=ACT_NONE, act_param=0.0, save=True, R=None):
+    """Row LayerNorm: y = act(mask*(xhat*w+b)) + R. -> y, mean, rstd."""
+    _chk(x, w, b, mask, R)
     rows, D = x.shape
     y = torch.empty_like(x)
     mean = new((rows,), x) if save else None
     rstd = new((rows,), x) if save else None
-    _lib.call("fl_layernorm_fwd", _p(x), _p(w), _p(b), _p(mask), _p(y), _p(mean), _p(rstd), rows, D, float(eps), act,
+    _lib.call("fl_layernorm_fwd", _p(x), _p(w), _p(b), _p(mask), _p(R), _p(y), _p(mean), _p(rstd), rows, D, float(eps), act,
               float(act_param), _stream())
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, b, mask, mean, rstd, act=ACT_NONE, act_param=0.0):
-    _chk(dy, x, w, b, mask, mean, rstd)
+def layernorm_bwd(dy, x, w, b, mask, mean, rstd, act=ACT_NONE, act_param=0.0, R=None, dw_out=None, db_out=None):
+    _chk(dy, x, w, b, mask, mean, rstd, R, dw_out, db_out)
     rows, D = x.shape
     dx = torch.empty_like(x)
-    dw, db = new((D,), x), new((D,), x)
+    dw = dw_out if dw_out is not None else new((D,), x)
+    db = db_out if db_out is not None else new((D,), x)
     wsp, wsn = _ws(_lib.load().fl_layernorm_bwd_workspace_bytes(rows, D), x)
-    _lib.call("fl_layernorm_bwd", _p(dy), _p(x), _p(w), _p(b), _p(mask), _p(mean), _p(rstd), _p(dx), _p(dw), _p(db),
+    _lib.call("fl_layernorm_bwd", _p(dy), _p(x), _p(w), _p(b), _p(mask), _p(mean), _p(rstd), _p(R), _p(dx), _p(dw), _p(db),
               rows, D, act, float(act_param), wsp, wsn, _stream())
     return dx, dw, db
 
@@ -296,7 +314,8 @@ def res_tail_map(y, scale=None, shift=None, s=None):
     _chk(y, scale, shift, s)
     B, H, W, C = y.shape
     m = new((B, 2, H, W), y)
-    _lib.call("fl_res_tail_map", _p(y), _p(scale), _p(shift), _p(s), _p(m), B, H * W, C, _stream())
+    spi = int(s is not None and s.dim() == 2)  # s (B,C): per image; s (C,): one gate vector for the batch
+    _lib.call("fl_res_tail_map", _p(y), _p(scale), _p(shift), _p(s), spi, _p(m), B, H * W, C, _stream())
     return m
 
 
@@ -305,8 +324,9 @@ def res_tail_out(y, scale=None, shift=None, s=None, map_=None, saw=None, xres=No
     B, H, W, C = y.shape
     out = torch.empty_like(y)
     att = new((B, H, W), y) if save_att else None
-    _lib.call("fl_res_tail_out", _p(y), _p(scale), _p(shift), _p(s), _p(map_), _p(saw), _p(xres), _p(out), _p(att), B, H,
-              W, C, int(final_swish), _stream())
+    spi = int(s is not None and s.dim() == 2)
+    _lib.call("fl_res_tail_out", _p(y), _p(scale), _p(shift), _p(s), spi, _p(map_), _p(saw), _p(xres), _p(out), _p(att),
+              B, H, W, C, int(final_swish), _stream())
     return (out, att) if save_att else out
 
 
@@ -395,9 +415,9 @@ def embedding_fwd(table, idx):
     return out
 
 
-def embedding_bwd(dout, idx, rows):
-    _chk(dout, idx)
-    dt = new((rows, dout.shape[1]), dout)
+def embedding_bwd(dout, idx, rows, out=None):
+    _chk(dout, idx, out)
+    dt = out if out is not None else new((rows, dout.shape[1]), dout)
     _lib.call("fl_embedding_bwd", _p(dout), _p(idx), _p(dt), idx.shape[0], dout.shape[1], rows, _stream())
     return dt
 

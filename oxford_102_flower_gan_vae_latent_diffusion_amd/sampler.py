@@ -1,0 +1,57 @@
+"""DDPM reverse process (v2:594-598) as a replayed hipGraph.
+
+The reference's loop makes a tensor->bool host sync every step (`if t[0] > 0`, v2:588) and launches ~100
+eager kernels per step. Here one reverse step = denoiser forward + Philox noise + fused update + device-side
+step counter is captured once and replayed; `t` lives in device memory (int32 for the update kernel, int64 for
+the time embedding), so there is no host round trip inside the 1000-step loop."""
+import torch
+
+from . import engine, ops
+
+
+class GraphSampler:
+    def __init__(self, diffusion, shape, device, c=None, use_graph=True):
+        self.d = diffusion
+        self.shape = tuple(shape)
+        self.device = torch.device(device)
+        self.c = c.long().contiguous() if c is not None else None
+        self.use_graph = use_graph
+        self.graph = None
+
+    def _step(self):
+        d = self.d
+        eps, _ = engine.unet_forward(d.eps_model, self.x, self.t64, self.c, None, None, save=False)
+        d.rng.normal(self.shape, self.device, out=self.noise)
+        ops.p_sample_update(self.x, eps, self.noise, self.t32, d.alpha, d.alpha_bar, d.beta, out=self.x)
+        ops.step_counter_add(self.t32, self.t64, -1)
+
+    @torch.no_grad()
+    def run(self, x_T=None, n_steps=None, t_start=None):
+        d = self.d
+        was_training = getattr(d.eps_model, "training", False)
+        if was_training:
+            d.eps_model.eval()
+        n_steps = d.n_steps if n_steps is None else n_steps
+        t0 = (d.n_steps - 1) if t_start is None else t_start
+        self.x = d.rng.normal(self.shape, self.device) if x_T is None else x_T.to(self.device, torch.float32).clone()
+        self.noise = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        self.t32 = torch.tensor([t0], dtype=torch.int32, device=self.device)
+        self.t64 = torch.tensor([t0], dtype=torch.int64, device=self.device)
+        done = 0
+        if n_steps > 0:
+            self._step()  # eager first step: sizes the workspace, warms every kernel
+            done = 1
+        if self.use_graph and n_steps - done > 1:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step()
+            self.graph = g
+            for _ in range(n_steps - done):
+                g.replay()
+        else:
+            for _ in range(n_steps - done):
+                self._step()
+        if was_training:
+            d.eps_model.train()
+        return self.x

@@ -1,0 +1,205 @@
+"""Module-level parity on the GPU: the drop-in modules vs the golden vectors generated from the reference and
+vs the CPU oracle on identical inputs / explicit noise. Tolerances are fp32 re-association; the north-star
+criterion (eps-MSE <= 1e-4) is asserted explicitly."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import procedural_init as pinit  # noqa: E402
+from oracle import v2_oracle as O  # noqa: E402
+from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M  # noqa: E402
+from oxford_102_flower_gan_vae_latent_diffusion_amd import steps  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, name + ".npz")).items()}
+
+
+def close(a, b, tol, what=""):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = max(1.0, b.abs().max().item())
+    assert err <= tol * ref, "%s: max err %.3e (ref max %.3e)" % (what, err, ref)
+
+
+def seeded(module, seed):
+    module.load_state_dict(pinit.procedural_state_dict(module.state_dict(), seed))
+    return module
+
+
+@pytest.fixture(scope="module")
+def ae(dev):
+    return seeded(M.SimpleAutoencoder(), 42).to(dev).eval()
+
+
+@pytest.fixture(scope="module")
+def unet(dev):
+    return seeded(M.ConditionalUNet(), 44).to(dev).eval()
+
+
+def test_primitives_vs_reference(dev, ae):
+    f = load("primitives")
+    x = f["x"].to(dev)
+    rb = ae.encoder.res1
+    with torch.no_grad():
+        close(M.Swish()(x), f["swish"], 1e-6, "swish")
+        close(rb.ca(x), f["ca"], 2e-5, "ca")
+        close(rb.sa(x), f["sa"], 2e-5, "sa")
+        close(rb.ln1(x), f["ln2d"], 2e-5, "ln2d")
+        close(rb(x), f["resblock"], 5e-5, "resblock")
+
+
+def test_autoencoder_vs_reference(dev, ae):
+    f = load("autoencoder")
+    with torch.no_grad():
+        mu, logvar = ae.encoder(f["data"].to(dev))
+        close(mu, f["mu"], 1e-4, "mu")
+        close(logvar, f["logvar"], 1e-4, "logvar")
+        feats = ae.encoder.skip_features
+        assert [tuple(x.shape) for x in feats] == [(2, 64, 64, 64), (2, 128, 32, 32), (2, 256, 16, 16), (2, 512, 8, 8)]
+        close(feats[3], f["feat3"], 1e-4, "feat3")
+        close(torch.stack([x.abs().mean() for x in feats]), f["feat_absmean"], 2e-5, "feature abs-means")
+        mu2, lvc = ae.encode_with_params(f["data"].to(dev))
+        close(lvc, f["logvar_clamped"], 1e-4, "clamped logvar")
+        z = ae.reparameterize(f["mu"].to(dev), f["logvar"].to(dev), f["eps"].to(dev))
+        close(z, f["z"], 1e-6, "z")
+        close(ae.reparameterize(f["mu"].to(dev), f["logvar"].to(dev), f["eps777"].to(dev)), f["z777"], 1e-6, "z777")
+        recon = ae.decode(f["z"].to(dev))
+        assert recon.shape == (2, 3, 64, 64)
+        close(recon, f["recon"], 1e-4, "recon")
+        assert ((recon.cpu() - f["recon"]) ** 2).mean().item() < 1e-8
+        close(ae.kl_divergence(f["mu"].to(dev) * 6, f["logvar"].to(dev) * 3), f["kl"], 2e-5, "kl")
+        close(ae.compute_center_loss(f["z"].to(dev), f["labels"].to(dev)), f["center_loss"], 1e-5, "center loss")
+        close(M.euclidean_distance_loss(f["recon"].to(dev), f["data"].to(dev)), f["recon_loss"], 1e-6, "euclid")
+        close(M.euclidean_distance_loss(f["recon"].to(dev), f["data"].to(dev), "none"), f["recon_norms"], 1e-6, "euclid none")
+        centers = ae.class_centers.clone()
+        ae.update_centers(f["z"].to(dev), f["labels"].to(dev), momentum=0.9)
+        close(ae.class_centers[f["labels"].to(dev)], f["centers_after"], 1e-6, "update_centers")
+        ae.class_centers.copy_(centers)
+        # full forward with explicit noise
+        r, mu3, lv3, z3 = ae(f["data"].to(dev), eps=f["eps"].to(dev))
+        close(r, f["recon"], 2e-4, "forward recon")
+
+
+def test_unet_vs_reference(dev, unet):
+    f = load("unet")
+    x, t, c = f["x"].to(dev), f["t"].to(dev), f["c"].to(dev)
+    with torch.no_grad():
+        e = unet(x, t, c)
+        close(e, f["eps_full"], 5e-5, "eps per-sample t")
+        assert ((e.cpu() - f["eps_full"]) ** 2).mean().item() <= 1e-4  # north-star parity criterion
+        assert ((e.cpu() - f["eps_full"]) ** 2).mean().item() <= 1e-9   # what fp32 MFMA actually achieves
+        close(unet(x, torch.tensor([437], device=dev), c), f["eps_shared"], 5e-5, "eps shared t")
+        close(unet(x, t, None), f["eps_nocls"], 5e-5, "eps no class")
+    d = M.ConditionalDenoiseDiffusion(unet, n_steps=1000, device=dev)
+    close(d.beta, f["beta"], 0, "beta")
+    close(d.alpha_bar, f["alpha_bar"], 0, "alpha_bar")
+    close(d.q_sample(x, t, f["noise_q"].to(dev)), f["xt"], 1e-6, "q_sample")
+    xx = f["traj"][0].to(dev)
+    cc = f["traj_c"].to(dev)
+    for i, tt in enumerate(reversed(range(20))):
+        xx = d.p_sample(xx, tt, cc, noise=f["traj_noise"][i].to(dev))
+        close(xx, f["traj"][i + 1], 2e-4, "p_sample t=%d" % tt)
+    with torch.no_grad():
+        close(d.loss(x, c, t=f["loss_t"].to(dev), eps=f["loss_eps"].to(dev)), f["loss"], 2e-5, "ddpm loss")
+
+
+def test_unet_backward_vs_oracle_autograd(dev):
+    """Gradients of the manual backward chain vs torch autograd on the oracle, train-mode masks explicit."""
+    B = 8
+    un = seeded(M.ConditionalUNet(), 44).to(dev).train()
+    sd = {k: v.detach().cpu().double() for k, v in un.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x, eps = torch.randn(B, 256, generator=g), torch.randn(B, 256, generator=g)
+    t, c = torch.randint(0, 1000, (B,), generator=g), torch.randint(0, 102, (B,), generator=g)
+    dims = [256, 512, 1024, 512]
+    bm = [(torch.rand(B, d, generator=g) > 0.3).float() / 0.7 for d in dims]
+    hm = [(torch.rand(B, 8, generator=g) > 0.3).float() / 0.7 for _ in dims]
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    out = O.unet_forward(sdg, x.double(), t, c, [m.double() for m in bm], [m.double() for m in hm])
+    loss = O.euclidean_distance_loss(eps.double(), out)
+    loss.backward()
+    xd = x.to(dev).requires_grad_(True)
+    o = un(xd, t.to(dev), c.to(dev), [m.to(dev) for m in bm], [m.to(dev) for m in hm])
+    close(o, out, 5e-5, "train-mode forward")
+    l = M.euclidean_distance_loss(eps.to(dev), o)
+    close(l, loss, 2e-5, "loss")
+    l.backward()
+    for n, p in un.named_parameters():
+        ref = sdg[n].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        close(p.grad, ref, 2e-4, "grad " + n)
+    # q/k rows get exactly zero
+    assert float(un.attention_layers[1].in_proj_weight.grad[:1024].abs().max()) == 0.0
+
+
+def test_ddpm_trainer_vs_reference_loop(dev):
+    """Two iterations of the build's ddpm step vs the reference's own train_conditional_diffusion loop."""
+    f = load("ddpm_loop")
+    ae = seeded(M.SimpleAutoencoder(), 42).to(dev).eval()
+    un = seeded(M.ConditionalUNet(), 44).to(dev).eval()
+    tr = steps.DDPMTrainer(ae, un, lr=1e-3)
+    losses = []
+    for i in range(2):
+        l = tr.step(f["data%d" % i].to(dev), f["labels%d" % i].to(dev), f["reparam_eps%d" % i].to(dev),
+                    f["t%d" % i].to(dev), f["eps%d" % i].to(dev))
+        losses.append(float(l))
+    close(np.mean(losses), f["epoch_loss"], 5e-5, "epoch mean loss")
+    sd = un.state_dict()
+    for k in [k for k in f if "__" in k or k == "residual_weight"]:
+        key = k.replace("__", ".")
+        close(sd[key].reshape(-1)[:64], f[k], 3e-4, "post-step " + key)
+
+
+def test_autograd_path_matches_trainer(dev):
+    """The reference-style loop (loss.backward(); clip_grad_norm_; torch AdamW) on the drop-in modules gives the
+    same update as the fused trainer."""
+    f = load("ddpm_loop")
+    ae = seeded(M.SimpleAutoencoder(), 42).to(dev).eval()
+    un = seeded(M.ConditionalUNet(), 44).to(dev).eval()
+    d = M.ConditionalDenoiseDiffusion(un, n_steps=1000, device=dev)
+    opt = torch.optim.AdamW(un.parameters(), lr=1e-3, weight_decay=1e-5, betas=(0.9, 0.999))
+    tot = 0.0
+    for i in range(2):
+        with torch.no_grad():
+            mu, logvar = ae.encode_with_params(f["data%d" % i].to(dev))
+            z = ae.reparameterize(mu, logvar, f["reparam_eps%d" % i].to(dev))
+        loss = d.loss(z, f["labels%d" % i].to(dev), t=f["t%d" % i].to(dev), eps=f["eps%d" % i].to(dev))
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(un.parameters(), max_norm=1.0)
+        opt.step()
+        tot += loss.item()
+    close(tot / 2, f["epoch_loss"], 5e-5, "epoch mean loss")
+    sd = un.state_dict()
+    for k in [k for k in f if "__" in k or k == "residual_weight"]:
+        key = k.replace("__", ".")
+        close(sd[key].reshape(-1)[:64], f[k], 3e-4, "post-step " + key)
+
+
+def test_sampler_graph_equals_eager_and_oracle(dev, unet):
+    B = 4
+    c = torch.tensor([0, 5, 50, 101], device=dev)
+    x_T = torch.randn(B, 256, generator=torch.Generator().manual_seed(3))
+    d = M.ConditionalDenoiseDiffusion(unet, n_steps=1000, device=dev)
+    from oxford_102_flower_gan_vae_latent_diffusion_amd.sampler import GraphSampler
+    d.rng.manual_seed(99)
+    a = GraphSampler(d, (B, 256), dev, c, use_graph=True).run(x_T, n_steps=12, t_start=11).clone()
+    d.rng.manual_seed(99)
+    b = GraphSampler(d, (B, 256), dev, c, use_graph=False).run(x_T, n_steps=12, t_start=11).clone()
+    assert torch.equal(a, b), "graph replay must be bit-identical to eager"
+    assert torch.isfinite(a).all()
+    # full-length API smoke (short schedule): sample() and its alias
+    d2 = M.ConditionalDenoiseDiffusion(unet, n_steps=8, device=dev)
+    s = d2.sample((B, 256), dev, c)
+    assert s.shape == (B, 256) and torch.isfinite(s).all()
+    assert d2.p_sample_loop.__func__ is d2.sample.__func__
