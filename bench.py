@@ -21,6 +21,14 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 den
 GFLOP_PER_IMAGE_STEP = 2.748
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 def conv_shapes(B):
     """The launches of the dominant kernel gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> in one step:
     (name, B,H,W,Cin,Cout,k,stride,pad). Algorithmic FLOP per launch = 2*B*Ho*Wo*Cout*k*k*Cin."""
@@ -134,9 +142,11 @@ def main():
         labels.append(l)
     sdata, slabels = batches[0].clone(), labels[0].clone()
 
+    log("models + synthetic batches resident in HBM (B=%d per GPU)" % B)
     use_graph = not a.no_graph
     if use_graph:
         tr.capture(sdata, slabels)
+        log("hipGraph captured")
 
     def one_step(i):
         if use_graph:
@@ -147,6 +157,8 @@ def main():
 
     for i in range(a.warmup):
         one_step(i)
+    torch.cuda.synchronize(dev)
+    log("warm-up done")
 
     def barrier():
         if world > 1:
@@ -168,6 +180,7 @@ def main():
         dt = float(tt)
     final_loss = float(loss)
     assert final_loss == final_loss, "loss is NaN"
+    log("timed region: %d steps in %.3f s (loss %.4f)" % (a.steps, dt, final_loss))
 
     out = {
         "metric": "images/sec VAE+UNet train step, 64x64 bs256",
@@ -195,6 +208,7 @@ def main():
     if rank == 0 and world == 1:
         if not a.no_roofline:
             r = measure_dominant_kernel(dev, B)
+            log("dominant kernel: %.1f TFLOP/s avg over %d launches" % (r["tflops"], r["launches"]))
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": "gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
@@ -210,7 +224,9 @@ def main():
             }
         if not a.no_cpu_baseline:
             threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(threads)
+            log("timing the CPU oracle on %d host threads ..." % threads)
+            out["cpu_baseline"] = cpu_baseline(min(threads, 64))
+            log("cpu baseline done")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

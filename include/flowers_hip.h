@@ -130,6 +130,9 @@ int fl_groupnorm_bwd(const float* dy, const float* x, const float* scale, const 
 int fl_batchnorm_bwd(const float* dy, const float* x, const float* scale, const float* shift, const float* w,
                      const float* mean, const float* rstd, int act, float act_param, float* dx, float* dw, float* db,
                      float* coef, int B, int HW, int C, void* ws, size_t ws_bytes, fl_stream_t stream);
+/* per-image channel sums: out1[b,c] = sum_pix a, out2[b,c] = sum_pix a*x, a = dy (or x if dy NULL) — v2:56,65 */
+int fl_chan_sums(const float* x, const float* dy, float* out1, float* out2, int B, int HW, int C, void* ws,
+                 size_t ws_bytes, fl_stream_t stream);
 /* nn.LayerNorm over the last dim (v2:212,218,248,251,313,317,521,525,530):
  * y = act(mask * (xhat*w + b)) + R; mask (rows,D) optional = dropout scale (v2:522);
  * R optional residual (v2:548).  Backward: dx = LN'(dy) + R. */
@@ -216,6 +219,29 @@ int fl_gather_rows(const float* table, const int64_t* idx, float* out, int B, in
 int fl_update_centers(float* centers, const float* z, const int64_t* labels, float momentum, int B, int D, int classes,
                       fl_stream_t stream);                                                            /* v2:369-378 */
 int fl_balance_losses(const float* terms, const float* weights, float* coeff, float* total, fl_stream_t stream); /* v2:1107-1125 */
+
+/* ------------------------------------------------------------------------ *
+ * Backward of the residual-block tail (v2:173-177) and VAE-GAN-only helpers.
+ *   A: dw = dout*swish'(u*att + x) ; da = att(1-att) * sum_c dw*u
+ *   conv: dmap = conv7x7^T(da), dsaw = sum da (x) map
+ *   C: dn = s * (dw*att + dmap0/C + [argmax] dmap1)   (feeds fl_instnorm_bwd)
+ * ------------------------------------------------------------------------ */
+int fl_res_tail_bwd_a(const float* dout, const float* y, const float* scale, const float* shift, const float* s,
+                      int s_per_image, const float* att, const float* xres, int final_swish, float* dw, float* da,
+                      int B, int HW, int C, fl_stream_t stream);
+int fl_res_tail_bwd_c(const float* dw, const float* y, const float* scale, const float* shift, const float* s,
+                      int s_per_image, const float* att, const float* dmap, float* dn, int B, int HW, int C,
+                      fl_stream_t stream);
+int fl_sa_conv_bwd(const float* da, const float* map, const float* saw, float* dmap, float* dsaw, int B, int H, int W,
+                   fl_stream_t stream);
+/* ds[c] = (w_ln*dw_ln + b_ln*db_ln)/s : gradient of the batch-shared channel-attention gate (v2:65-67) */
+int fl_ca_gate_grad(const float* lnw, const float* lnb, const float* dlnw, const float* dlnb, const float* s, float* ds,
+                    int C, fl_stream_t stream);
+int fl_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, fl_stream_t stream);    /* VGG16, v2:965 */
+int fl_maxpool2_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, fl_stream_t stream);
+int fl_mul(const float* a, const float* b, float* out, int64_t n, fl_stream_t stream);            /* nn.Dropout v2:315,319 */
+int fl_clamp_bwd(const float* d, const float* x, float lo, float hi, float* out, int64_t n, fl_stream_t stream); /* v2:352 */
+int fl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, int64_t n, fl_stream_t stream); /* v2:339-343 */
 
 #ifdef __cplusplus
 }

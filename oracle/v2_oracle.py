@@ -172,7 +172,7 @@ def time_features(t, n_channels=256):
 
 def time_embedding(sd, p, t):
     """TimeEmbedding v2:401-418."""
-    e = time_features(t)
+    e = time_features(t).to(sd[p + "lin1.weight"].dtype)  # features are fp32 (v2:412-414); fp64 only in gradient checks
     e = swish(F.linear(e, sd[p + "lin1.weight"], sd[p + "lin1.bias"]))
     return F.linear(e, sd[p + "lin2.weight"], sd[p + "lin2.bias"])
 

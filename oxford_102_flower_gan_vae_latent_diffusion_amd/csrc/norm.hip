@@ -578,3 +578,28 @@ int fl_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
 }
 
 }  // extern "C"
+
+namespace {
+__global__ void chan_sums_finalize(const float* partial, float* out1, float* out2, int B, int C, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  double s1, s2;
+  sum_slabs(partial, b, S, C, c, s1, s2);
+  if (out1) out1[i] = (float)s1;
+  if (out2) out2[i] = (float)s2;
+}
+}  // namespace
+
+extern "C" {
+// out1[b,c] = sum_pix a, out2[b,c] = sum_pix a*x with a = dy (a = x when dy is NULL): per-image channel sums
+// (AdaptiveAvgPool2d(1) of v2:56,65 and its backward).
+int fl_chan_sums(const float* x, const float* dy, float* out1, float* out2, int B, int HW, int C, void* ws,
+                 size_t ws_bytes, fl_stream_t stream) {
+  NORM_CHECKS("fl_chan_sums");
+  int rc = run_partial(dy ? 1 : 0, x, dy, nullptr, nullptr, 0, 0, 0.f, partial, B, HW, C, sl, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(chan_sums_finalize, dim3(fl::cdiv((long long)B * C, 256)), dim3(256), 0, st, partial, out1, out2, B, C, sl.S);
+  return fl::check_launch("chan_sums_finalize");
+}
+}  // extern "C"

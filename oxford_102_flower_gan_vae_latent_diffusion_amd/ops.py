@@ -571,6 +571,90 @@ def update_centers(centers, z, labels, momentum=0.9):
               centers.shape[0], _stream())
 
 
+def res_tail_bwd_a(dout, y, scale, shift, s, att, xres, final_swish=True, want_da=True):
+    """-> dw (B,H,W,C), da (B,H,W) or None."""
+    _chk(dout, y, scale, shift, s, att, xres)
+    B, H, W, C = y.shape
+    dw = torch.empty_like(y)
+    da = new((B, H, W), y) if (want_da and att is not None) else None
+    _lib.call("fl_res_tail_bwd_a", _p(dout), _p(y), _p(scale), _p(shift), _p(s), int(s is not None and s.dim() == 2),
+              _p(att), _p(xres), int(final_swish), _p(dw), _p(da), B, H * W, C, _stream())
+    return dw, da
+
+
+def res_tail_bwd_c(dw, y, scale, shift, s, att, dmap):
+    _chk(dw, y, scale, shift, s, att, dmap)
+    B, H, W, C = y.shape
+    dn = torch.empty_like(y)
+    _lib.call("fl_res_tail_bwd_c", _p(dw), _p(y), _p(scale), _p(shift), _p(s), int(s is not None and s.dim() == 2),
+              _p(att), _p(dmap), _p(dn), B, H * W, C, _stream())
+    return dn
+
+
+def sa_conv_bwd(da, map_, saw, want_dsaw=True):
+    _chk(da, map_, saw)
+    B, H, W = da.shape
+    dmap = new((B, 2, H, W), da)
+    dsaw = new((1, 2, 7, 7), da) if want_dsaw else None
+    _lib.call("fl_sa_conv_bwd", _p(da), _p(map_), _p(saw), _p(dmap), _p(dsaw), B, H, W, _stream())
+    return dmap, dsaw
+
+
+def ca_gate_grad(lnw, lnb, dlnw, dlnb, s):
+    _chk(lnw, lnb, dlnw, dlnb, s)
+    ds = torch.empty_like(s)
+    _lib.call("fl_ca_gate_grad", _p(lnw), _p(lnb), _p(dlnw), _p(dlnb), _p(s), _p(ds), s.numel(), _stream())
+    return ds
+
+
+def chan_dot(dy, x):
+    """(B,C): sum over pixels of dy*x (NHWC)."""
+    _chk(dy, x)
+    B, H, W, C = x.shape
+    out = new((B, C), x)
+    wsp, wsn = _norm_ws(B, H * W, C, x)
+    _lib.call("fl_chan_sums", _p(x), _p(dy), None, _p(out), B, H * W, C, wsp, wsn, _stream())
+    return out
+
+
+def maxpool2_fwd(x):
+    _chk(x)
+    B, H, W, C = x.shape
+    y = new((B, H // 2, W // 2, C), x)
+    _lib.call("fl_maxpool2_fwd", _p(x), _p(y), B, H, W, C, _stream())
+    return y
+
+
+def maxpool2_bwd(dy, x):
+    _chk(dy, x)
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _lib.call("fl_maxpool2_bwd", _p(dy), _p(x), _p(dx), B, H, W, C, _stream())
+    return dx
+
+
+def mul(a, b, out=None):
+    _chk(a, b, out)
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.call("fl_mul", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def clamp_bwd(d, x, lo, hi):
+    _chk(d, x)
+    out = torch.empty_like(x)
+    _lib.call("fl_clamp_bwd", _p(d), _p(x), float(lo), float(hi), _p(out), x.numel(), _stream())
+    return out
+
+
+def reparam_bwd(dz, logvar, eps):
+    _chk(dz, logvar, eps)
+    out = torch.empty_like(logvar)
+    _lib.call("fl_reparam_bwd", _p(dz), _p(logvar), _p(eps), _p(out), logvar.numel(), _stream())
+    return out
+
+
 def balance_losses(terms, weights):
     _chk(terms, weights)
     coeff, total = new((6,), terms), new((1,), terms)

@@ -1,39 +1,53 @@
 """Training-step harnesses (the build's counterpart of the reference's loop bodies).
 
-ddpm step  = v2:1254-1264: frozen-encoder forward -> reparameterize -> q_sample -> denoiser fwd/bwd ->
-             global-norm clip (1.0) -> AdamW(lr, wd 1e-5), with every host sync of the reference removed
-             (loss, norm, clip coefficient, step count and lr stay on the device), one RCCL all-reduce of the
-             flat gradient buffer per step when data-parallel, and optional hipGraph capture of the whole step.
+ddpm step    = v2:1254-1264: frozen-encoder forward -> reparameterize -> q_sample -> denoiser fwd/bwd ->
+               global-norm clip (1.0) -> AdamW(lr, wd 1e-5).
+vae-gan step = v2:1060-1134: AE forward, 6 loss terms, D update (before the generator's adversarial term),
+               device-side loss balancing, AE backward, clip, AdamW, centre EMA.
+Every host sync of the reference (.item(), clip_grad_norm_) is removed: losses, norms, clip coefficient, balancing
+scales, step count and lr stay on the device. Data-parallel runs add ONE RCCL all-reduce of the flat gradient
+buffer per step; the ddpm step can be replayed as hipGraphs.
 """
 import torch
 
-from . import engine, ops
+from . import engine, engine_bwd, ops
 
 
 class FlatParams:
     """Re-homes a module's parameters into ONE flat fp32 buffer (grads into another), 16-byte aligned slots.
     Parameters stay real nn.Parameters (views), so state_dict()/load_state_dict()/torch.optim keep working.
-    Parameters named in `inactive` (never touched by the forward: grad None in the reference, skipped by its
-    optimizer) are placed last and excluded from clip / AdamW / all-reduce."""
+    Parameters whose name starts with one of `tail_prefixes` are placed last, in the given prefix order, so that an
+    optimizer can exclude them (parameters the forward never touches get grad None in the reference and are skipped
+    by its optimizer: `n_upto(prefix)` gives the length of the buffer before that group)."""
 
-    def __init__(self, module, inactive_prefixes=()):
+    def __init__(self, module, tail_prefixes=()):
         named = list(module.named_parameters())
-        act = [(n, p) for n, p in named if not any(n.startswith(x) for x in inactive_prefixes)]
-        ina = [(n, p) for n, p in named if any(n.startswith(x) for x in inactive_prefixes)]
+
+        def group(n):
+            for gi, pfx in enumerate(tail_prefixes):
+                if n.startswith(pfx):
+                    return gi + 1
+            return 0
+
+        order = sorted(range(len(named)), key=lambda i: (group(named[i][0]), i))
         dev = named[0][1].device
-        self.slots = {}
+        self.slots, self._starts = {}, {}
         off = 0
-        for n, p in act + ina:
+        for i in order:
+            n, p = named[i]
+            gi = group(n)
+            if gi and tail_prefixes[gi - 1] not in self._starts:
+                self._starts[tail_prefixes[gi - 1]] = off
             self.slots[n] = (off, p.numel(), tuple(p.shape))
             off += (p.numel() + 3) // 4 * 4
-            if n == act[-1][0]:
-                self.n_active = off
         self.n_total = off
+        first_tail = min(self._starts.values()) if self._starts else off
+        self.n_active = first_tail
         self.flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
         self.gviews = {}
         with torch.no_grad():
-            for n, p in act + ina:
+            for n, p in named:
                 o, k, shp = self.slots[n]
                 v = self.flat[o:o + k].view(shp)
                 v.copy_(p.data)
@@ -42,6 +56,21 @@ class FlatParams:
                 self.gviews[n] = gv
                 p.grad = gv
         self.module = module
+
+    def n_upto(self, prefix):
+        return self._starts.get(prefix, self.n_total)
+
+    def set_grads(self, G, prefix=""):
+        """copy a {name: grad} dict into the flat gradient buffer."""
+        for n, g in G.items():
+            if g is not None:
+                ops.axpby(1.0, g.contiguous(), out=self.gviews[prefix + n])
+
+    def add_grads(self, G, prefix=""):
+        for n, g in G.items():
+            if g is not None:
+                v = self.gviews[prefix + n]
+                ops.axpby(1.0, g.contiguous(), 1.0, v, out=v)
 
     def bump(self):
         """Parameters were updated through raw pointers: invalidate derived (packed) layouts."""
@@ -68,9 +97,9 @@ class FusedAdam:
     def set_lr(self, lr):
         self.lr.fill_(lr)
 
-    def step(self, gscale=1.0):
+    def step(self, gscale=1.0, n=None):
         fp = self.fp
-        n = fp.n_active
+        n = fp.n_active if n is None else n
         g = fp.grad[:n]
         coef = None
         if self.max_norm is not None:
@@ -86,9 +115,6 @@ class FusedAdam:
         fp.bump()
 
 
-UNET_INACTIVE = ("time_projections.4.", "attention_layers.4.")
-
-
 class DDPMTrainer:
     """Latent-DDPM training step (configs 3/4 of BASELINE.json)."""
 
@@ -100,7 +126,8 @@ class DDPMTrainer:
         self.dev = dev
         self.diffusion = ConditionalDenoiseDiffusion(unet, n_steps=n_steps, device=dev)
         n_layers = len(unet.layers)
-        inactive = tuple(p for p in ("time_projections.%d." % n_layers, "attention_layers.%d." % n_layers))
+        # never touched by the forward (v2:540-553 loops over len(layers)): grad None in the reference
+        inactive = ("time_projections.%d." % n_layers, "attention_layers.%d." % n_layers)
         self.fp = FlatParams(unet, inactive)
         self.opt = FusedAdam(self.fp, lr, weight_decay=1e-5, decoupled=True, max_norm=1.0)
         self.pg, self.world = process_group, world_size
@@ -108,7 +135,6 @@ class DDPMTrainer:
         self.eps_theta = None
         self.graph = None
 
-    # -- pieces -------------------------------------------------------------------------------
     @torch.no_grad()
     def encode(self, data, reparam_eps=None):
         """v2:1257-1259 (frozen encoder, eval)."""
@@ -145,7 +171,6 @@ class DDPMTrainer:
     def update(self):
         self.opt.step(gscale=1.0 / self.world)
 
-    # -- whole step ---------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, data, labels, reparam_eps=None, t=None, eps=None, block_masks=None, head_masks=None):
         """Returns the loss as a device tensor (no host sync)."""
@@ -155,7 +180,7 @@ class DDPMTrainer:
         self.update()
         return self.loss
 
-    # -- hipGraph: capture [encode + fwd/bwd] and [clip + AdamW] around the (eager) all-reduce ----
+    # hipGraph: capture [encode + fwd/bwd] and [clip + AdamW] around the (eager) all-reduce
     def capture(self, data, labels):
         """data/labels become static input buffers; call replay() after copying new batches into them."""
         self.static_data, self.static_labels = data, labels
@@ -176,3 +201,123 @@ class DDPMTrainer:
         self.allreduce()
         self.g2.replay()
         return self.loss
+
+
+def loss_phase(epoch):
+    """Loss gating of v2:1072-1087 -> (kl_factor, cls_factor, center_factor)."""
+    if epoch < 40:
+        return 0.0, 0.0, 0.0
+    if epoch < 80:
+        return min(1.0, (epoch - 20) / 20), 0.0, 0.0
+    if epoch < 160:
+        return 1.0, min(0.2, (epoch - 40) / 20), 0.0
+    return 1.0, 1.0, min(1.0, (epoch - 60) / 20)
+
+
+def kl_weight_at(epoch, num_epochs, start=0.001, end=0.05):
+    """v2:1055."""
+    return min(end, start + (epoch / (num_epochs * 0.6)) * (end - start))
+
+
+class VAEGANTrainer:
+    """VAE-GAN training step (configs 1/2 of BASELINE.json), v2:1060-1134."""
+
+    def __init__(self, autoencoder, discriminator, vgg, lr=1e-4, lambda_cls=0.1, lambda_center=0.05, lambda_vgg=0.4,
+                 lambda_gan=0.2):
+        self.ae, self.disc, self.vgg = autoencoder, discriminator, vgg
+        dev = next(autoencoder.parameters()).device
+        self.dev = dev
+        self.fp = FlatParams(autoencoder, ("classifier.",))
+        self.opt = FusedAdam(self.fp, lr, weight_decay=1e-5, decoupled=True, max_norm=1.0)       # v2:1026, v2:1128
+        self.dfp = FlatParams(discriminator)
+        self.d_opt = FusedAdam(self.dfp, 1e-4, betas=(0.5, 0.999), weight_decay=0.0, decoupled=False)  # v2:1028
+        self.lam = (lambda_cls, lambda_center, lambda_vgg, lambda_gan)
+        self.terms = torch.zeros(6, dtype=torch.float32, device=dev)
+        self.weights = torch.zeros(6, dtype=torch.float32, device=dev)
+        self.out = {}
+
+    @torch.no_grad()
+    def step(self, data, labels, epoch=0, num_epochs=300, lr=None, reparam_eps=None, cls_masks=(None, None)):
+        ae, D, vgg = self.ae, self.disc, self.vgg
+        l_cls, l_cen, l_vgg, l_gan = self.lam
+        klw = kl_weight_at(epoch, num_epochs)
+        klf, clsf, cenf = loss_phase(epoch)
+        if lr is not None:
+            self.opt.set_lr(lr)
+        B = data.shape[0]
+        data = data.contiguous()
+        # ---- forward (v2:1069) ----
+        mu, logvar, feats, S_enc = engine_bwd.encoder_fwd(ae.encoder, data)
+        ae.encoder.skip_features = [f.permute(0, 3, 1, 2) for f in feats]
+        if reparam_eps is None:
+            reparam_eps = ae.rng.normal(mu.shape, mu.device)
+        z, _ = ops.reparameterize(mu, logvar, reparam_eps)
+        recon, S_dec = engine_bwd.decoder_fwd(ae.decoder, z)
+        # ---- losses (v2:1090-1094) ----
+        recon_loss, rn = ops.euclid_loss_fwd(recon, data)
+        fx, tape = engine_bwd.vgg_features(vgg, recon, True)
+        fy, _ = engine_bwd.vgg_features(vgg, data, False)
+        percep, pn = ops.euclid_loss_fwd(fx, fy)
+        zero = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        kl, kl_row = ops.kl_fwd(mu, logvar) if klf > 0 else (zero, None)
+        if clsf > 0:
+            m1, m2 = cls_masks
+            if ae.training and m1 is None:
+                c = ae.classifier
+                m1 = ae.rng.dropout((B, 512), z.device, c[3].p)
+                m2 = ae.rng.dropout((B, 256), z.device, c[7].p)
+            logits, S_cls = engine_bwd.classifier_fwd(ae, z, m1, m2)
+            ce, probs = ops.cross_entropy_fwd(logits, labels)
+        else:
+            ce = zero
+        if cenf > 0:
+            cb = ops.gather_rows(ae.class_centers, labels)
+            cen, cn = ops.euclid_loss_fwd(z, cb)
+        else:
+            cen = zero
+        # ---- discriminator update (v2:1097-1102) ----
+        p_real, S_r = engine_bwd.disc_fwd(D, data)
+        p_fake, S_f = engine_bwd.disc_fwd(D, recon)  # recon_x.detach(): no gradient reaches the AE from here
+        l_real, l_fake = ops.bce_fwd(p_real, 1.0), ops.bce_fwd(p_fake, 0.0)
+        d_loss = ops.axpby(0.5, l_real, 0.5, l_fake)
+        Gr, _ = engine_bwd.disc_bwd(D, S_r, ops.bce_bwd(p_real, 1.0, 0.5), need_wgrad=True, need_dx=False)
+        Gf, _ = engine_bwd.disc_bwd(D, S_f, ops.bce_bwd(p_fake, 0.0, 0.5), need_wgrad=True, need_dx=False)
+        self.dfp.set_grads(Gr)
+        self.dfp.add_grads(Gf)
+        self.d_opt.step()
+        # ---- generator adversarial term with the UPDATED discriminator (v2:1105) ----
+        p_adv, S_a = engine_bwd.disc_fwd(D, recon)
+        adv = ops.bce_fwd(p_adv, 1.0)
+        # ---- device-side loss balancing (v2:1107-1125) ----
+        for i, tsr in enumerate((recon_loss, percep, kl, adv, ce, cen)):
+            ops.axpby(1.0, tsr, out=self.terms[i:i + 1])
+        self.weights.copy_(torch.tensor([1.0, l_vgg, klw * klf, l_gan, l_cls * clsf, l_cen * cenf]))
+        coeff, total = ops.balance_losses(self.terms, self.weights)
+        # ---- backward of total_loss w.r.t. the autoencoder (v2:1127) ----
+        drecon = ops.euclid_loss_bwd(recon, data, rn, 1.0, coeff[0:1])
+        dfx = ops.euclid_loss_bwd(fx, fy, pn, 1.0, coeff[1:2])
+        drecon = engine_bwd._add(drecon, engine_bwd.vgg_features_bwd(vgg, tape, dfx))
+        _, dr_adv = engine_bwd.disc_bwd(D, S_a, ops.bce_bwd(p_adv, 1.0, 1.0, coeff[3:4]), need_wgrad=False, need_dx=True)
+        drecon = engine_bwd._add(drecon, dr_adv)
+        G_dec, dz = engine_bwd.decoder_bwd(ae.decoder, S_dec, drecon)
+        n_act = self.fp.n_upto("classifier.")
+        if clsf > 0:
+            G_cls, dz_cls = engine_bwd.classifier_bwd(ae, S_cls, ops.cross_entropy_bwd(probs, labels, 1.0, coeff[4:5]))
+            dz = engine_bwd._add(dz, dz_cls)
+            self.fp.set_grads(G_cls, "classifier.")
+            n_act = self.fp.n_total
+        if cenf > 0:
+            dz = engine_bwd._add(dz, ops.euclid_loss_bwd(z, cb, cn, 1.0, coeff[5:6]))
+        dmu, dlv = dz, ops.reparam_bwd(dz, logvar, reparam_eps)
+        if klf > 0:
+            dmu_k, dlv_k = ops.kl_bwd(mu, logvar, kl_row, 1.0, coeff[2:3])
+            dmu, dlv = engine_bwd._add(dmu, dmu_k), engine_bwd._add(dlv, dlv_k)
+        G_enc, _ = engine_bwd.encoder_bwd(ae.encoder, S_enc, dmu, dlv)
+        self.fp.set_grads(G_enc, "encoder.")
+        self.fp.set_grads(G_dec, "decoder.")
+        self.opt.step(n=n_act)                                   # clip 1.0 + AdamW (v2:1128-1129)
+        if epoch >= 60 and cenf > 0:                             # v2:1132-1134
+            ops.update_centers(ae.class_centers, z, labels, 0.9)
+        self.out = dict(total=total, recon=recon_loss, perceptual=percep, kl=kl, cls=ce, center=cen, adv=adv,
+                        d_loss=d_loss, recon_x=recon, mu=mu, logvar=logvar, z=z, grad_norm=self.opt.grad_norm)
+        return self.out
