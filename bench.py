@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
+    if os.environ.get("BENCH_WATCHDOG"):  # debugging aid: dump the python stack if a phase stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -223,9 +226,10 @@ def main():
                 "step_frac_of_mfma_roofline": (GFLOP_PER_IMAGE_STEP * B * a.steps / dt / 1e3) / FP32_MFMA_PEAK_TFLOPS,
             }
         if not a.no_cpu_baseline:
-            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            # one GPU's share of the host (the affinity mask of a shared 8-GPU host is much wider than this process should use)
+            threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
             log("timing the CPU oracle on %d host threads ..." % threads)
-            out["cpu_baseline"] = cpu_baseline(min(threads, 64))
+            out["cpu_baseline"] = cpu_baseline(threads)
             log("cpu baseline done")
     if rank == 0:
         print(json.dumps(out), flush=True)
