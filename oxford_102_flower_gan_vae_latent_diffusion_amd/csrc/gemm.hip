@@ -80,6 +80,17 @@ __device__ __forceinline__ float4 ld4g(const float* p, int nvalid, int vec) {
   return v;
 }
 
+// FAST: branch-free predicated vector load (clamped address + select) — legal when every valid float4 is whole
+// and 16-byte aligned; otherwise the guarded (slow, branchy) form handles tails / unaligned operands.
+template <bool FAST>
+__device__ __forceinline__ float4 ldsel(const float* p, bool ok, int nvalid, int vec, const float* safe) {
+  if constexpr (FAST) {
+    return ld4(ok ? p : safe);  // zeroing of !ok lanes is deferred to the LDS store (keeps the load in flight)
+  } else {
+    return ok ? ld4g(p, nvalid, vec) : zero4();
+  }
+}
+
 __device__ __forceinline__ float epilogue_value(const GArgs& g, float v, int col, const float* rptr) {
   if (g.bias) v += g.bias_scale * g.bias[col];
   if (rptr && g.r_pre) v += g.r_scale * (*rptr);
@@ -88,7 +99,7 @@ __device__ __forceinline__ float epilogue_value(const GArgs& g, float v, int col
   return v;
 }
 
-template <int BM, int BN, int WGM, int WGN, int AM, int BMODE>
+template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, bool FAST>
 __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
   static_assert(WGM * WGN == 4, "4 waves per block");
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -177,7 +188,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
     b_kx = tap - b_ky * g.kw;
   }
 
-  auto load_A = [&](int kc, float4 (&regs)[ANR]) {
+  auto load_A = [&](int kc, float4 (&regs)[ANR], unsigned& mask) {
+    mask = 0u;
     if constexpr (!A_KS) {
       const int k = kc * BK + kq;
       const int kleft = g.K - k;
@@ -196,38 +208,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
       }
 #pragma unroll
       for (int r = 0; r < ANR; ++r) {
-        bool ok = a_ok[r] && kleft > 0;
+        bool ok = a_ok[r] & (kleft > 0);
         if constexpr (AM != A_KC_PLAIN) {
-          ok = ok && (unsigned)(a_iy0[r] + dy) < (unsigned)g.H && (unsigned)(a_ix0[r] + dx) < (unsigned)g.W;
+          ok = ok & ((unsigned)(a_iy0[r] + dy) < (unsigned)g.H) & ((unsigned)(a_ix0[r] + dx) < (unsigned)g.W);
         }
-        regs[r] = ok ? ld4g(g.A + a_base[r] + off, kleft, g.a_vec) : zero4();
+        regs[r] = ldsel<FAST>(g.A + a_base[r] + off, ok, kleft, g.a_vec, g.A);
+        mask |= (ok ? 1u : 0u) << r;
       }
     } else {
 #pragma unroll
       for (int p = 0; p < ANR; ++p) {
         const int kk = kc * BK + a_ks_row + p * A_RPP;
         const int m = tile_m0 + a_ks_c;
-        const bool ok = kk < g.K && m < g.M;
-        regs[p] = ok ? ld4g(g.A + (long long)kk * g.lda + m, g.M - m, g.a_vec) : zero4();
+        const bool ok = (kk < g.K) & (m < g.M);
+        regs[p] = ldsel<FAST>(g.A + (long long)kk * g.lda + m, ok, g.M - m, g.a_vec, g.A);
+        mask |= (ok ? 1u : 0u) << p;
       }
     }
   };
 
-  auto load_B = [&](int kc, float4 (&regs)[BNR]) {
+  auto load_B = [&](int kc, float4 (&regs)[BNR], unsigned& mask) {
+    mask = 0u;
     if constexpr (BMODE == B_KC_PLAIN) {
       const int k = kc * BK + kq;
       const int kleft = g.K - k;
 #pragma unroll
       for (int r = 0; r < BNR; ++r) {
-        const bool ok = b_ok[r] && kleft > 0;
-        regs[r] = ok ? ld4g(g.B + b_base[r] + k, kleft, g.b_vec) : zero4();
+        const bool ok = b_ok[r] & (kleft > 0);
+        regs[r] = ldsel<FAST>(g.B + b_base[r] + k, ok, kleft, g.b_vec, g.B);
+        mask |= (ok ? 1u : 0u) << r;
       }
     } else {
       const int n = tile_n0 + b_ks_c;
 #pragma unroll
       for (int p = 0; p < BNR; ++p) {
         const int kk = kc * BK + b_ks_row + p * B_RPP;
-        bool ok = kk < g.K && n < g.N;
+        bool ok = (kk < g.K) & (n < g.N);
         const float* src = g.B;
         if constexpr (BMODE == B_KS_PLAIN) {
           src += (long long)kk * g.ldb + n;
@@ -248,32 +264,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
           const int img = kks / hw, pp = kks - img * hw;
           const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
           const int iy = oy * g.stride - g.pad + b_ky, ix = ox * g.stride - g.pad + b_kx;
-          ok = ok && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+          ok = ok & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
           src += (((long long)img * g.H + iy) * g.W + ix) * g.Cin + b_ci;
         }
-        regs[p] = ok ? ld4g(src, g.N - n, g.b_vec) : zero4();
+        regs[p] = ldsel<FAST>(src, ok, g.N - n, g.b_vec, g.B);
+        mask |= (ok ? 1u : 0u) << p;
       }
     }
   };
 
-  auto store_A = [&](int buf, const float4 (&regs)[ANR]) {
+  auto store_A = [&](int buf, const float4 (&regs)[ANR], unsigned mask) {
     float* S = As + buf * A_TILE;
 #pragma unroll
     for (int r = 0; r < ANR; ++r) {
+      const float4 v = (!FAST || ((mask >> r) & 1u)) ? regs[r] : zero4();
       if constexpr (!A_KS)
-        *reinterpret_cast<float4*>(S + (ld_row + 32 * r) * LDK + kq) = regs[r];
+        *reinterpret_cast<float4*>(S + (ld_row + 32 * r) * LDK + kq) = v;
       else
-        *reinterpret_cast<float4*>(S + (a_ks_row + r * A_RPP) * BM + a_ks_c) = regs[r];
+        *reinterpret_cast<float4*>(S + (a_ks_row + r * A_RPP) * BM + a_ks_c) = v;
     }
   };
-  auto store_B = [&](int buf, const float4 (&regs)[BNR]) {
+  auto store_B = [&](int buf, const float4 (&regs)[BNR], unsigned mask) {
     float* S = Bs + buf * B_TILE;
 #pragma unroll
     for (int r = 0; r < BNR; ++r) {
+      const float4 v = (!FAST || ((mask >> r) & 1u)) ? regs[r] : zero4();
       if constexpr (!B_KS)
-        *reinterpret_cast<float4*>(S + (ld_row + 32 * r) * LDK + kq) = regs[r];
+        *reinterpret_cast<float4*>(S + (ld_row + 32 * r) * LDK + kq) = v;
       else
-        *reinterpret_cast<float4*>(S + (b_ks_row + r * B_RPP) * BN + b_ks_c) = regs[r];
+        *reinterpret_cast<float4*>(S + (b_ks_row + r * B_RPP) * BN + b_ks_c) = v;
     }
   };
 
@@ -286,11 +305,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   float4 ra[ANR], rb[BNR];
+  unsigned ma = 0u, mb = 0u;
   if (kc_begin < kc_end) {
-    load_A(kc_begin, ra);
-    load_B(kc_begin, rb);
-    store_A(0, ra);
-    store_B(0, rb);
+    load_A(kc_begin, ra, ma);
+    load_B(kc_begin, rb, mb);
+    store_A(0, ra, ma);
+    store_B(0, rb, mb);
   }
   __syncthreads();
 
@@ -298,8 +318,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
   for (int kc = kc_begin; kc < kc_end; ++kc) {
     const bool more = kc + 1 < kc_end;
     if (more) {
-      load_A(kc + 1, ra);
-      load_B(kc + 1, rb);
+      load_A(kc + 1, ra, ma);
+      load_B(kc + 1, rb, mb);
     }
     const float* Sa = As + buf * A_TILE;
     const float* Sb = Bs + buf * B_TILE;
@@ -342,8 +362,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
         }
     }
     if (more) {
-      store_A(buf ^ 1, ra);
-      store_B(buf ^ 1, rb);
+      store_A(buf ^ 1, ra, ma);
+      store_B(buf ^ 1, rb, mb);
     }
     __syncthreads();
     buf ^= 1;
@@ -408,11 +428,11 @@ __global__ void splitk_reduce_kernel(const GArgs g) {
 }
 
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int AM, int BMODE>
-int launch_cfg(GArgs g, int classes, hipStream_t stream) {
+template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, bool FAST>
+int launch_cfg2(GArgs g, int classes, hipStream_t stream) {
   constexpr size_t lds = 2u * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
-  auto kern = gemm_kernel<BM, BN, WGM, WGN, AM, BMODE>;
+  auto kern = gemm_kernel<BM, BN, WGM, WGN, AM, BMODE, FAST>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -422,6 +442,16 @@ int launch_cfg(GArgs g, int classes, hipStream_t stream) {
   dim3 grid((unsigned)(tiles_m * g.tiles_n), (unsigned)classes, (unsigned)(g.splitk > 1 ? g.splitk : 1));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
   return fl::check_launch("gemm_kernel");
+}
+
+template <int BM, int BN, int WGM, int WGN, int AM, int BMODE>
+int launch_cfg(GArgs g, int classes, hipStream_t stream) {
+  bool fast = g.a_vec && g.b_vec;
+  if (AM != A_KS_PLAIN || BMODE == B_KC_PLAIN) fast = fast && (g.K % 4 == 0);  // a K-contiguous operand exists
+  if (AM == A_KS_PLAIN) fast = fast && (g.M % 4 == 0);
+  if (BMODE != B_KC_PLAIN) fast = fast && (g.N % 4 == 0);
+  if (fast) return launch_cfg2<BM, BN, WGM, WGN, AM, BMODE, true>(g, classes, stream);
+  return launch_cfg2<BM, BN, WGM, WGN, AM, BMODE, false>(g, classes, stream);
 }
 
 // tile-shape + split-K policy. `classes` = 4 for transposed conv, else 1.
