@@ -23,6 +23,7 @@
 // uses k = 4*(2q+h)+j of the 32-chunk, so A and B fragments always pair the same k.
 #include "fl_common.h"
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 
@@ -64,6 +65,7 @@ struct GArgs {
   int tiles_n;
   int splitk, chunks_per_split;
   float* ws;
+  int prio_mode;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -99,8 +101,12 @@ __device__ __forceinline__ float epilogue_value(const GArgs& g, float v, int col
   return v;
 }
 
-template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, bool FAST>
+// PATH 0: guarded loads (tails / unaligned operands); 1: branch-free vector loads, per-thread tap decode;
+// 2: as 1 + wave-uniform tap decode (Cin % 32 == 0: a 32-chunk never straddles a tap) kept in scalar registers.
+template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, int PATH>
 __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
+  constexpr bool FAST = PATH >= 1;
+  constexpr bool CHK = PATH == 2;
   static_assert(WGM * WGN == 4, "4 waves per block");
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -195,15 +201,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
       const int kleft = g.K - k;
       long long off = k;
       int dy = 0, dx = 0;
-      if constexpr (AM == A_KC_CONV) {
-        const int tap = k / g.Cin, c = k - tap * g.Cin;
-        dy = tap / g.kw;
-        dx = tap - dy * g.kw;
-        off = ((long long)dy * g.W + dx) * g.Cin + c;
-      } else if constexpr (AM == A_KC_TCONV) {
-        const int tap = k / g.Cin, c = k - tap * g.Cin;
-        dy = -(tap >> 1);
-        dx = -(tap & 1);
+      if constexpr (AM == A_KC_CONV || AM == A_KC_TCONV) {
+        int tap, c;
+        if constexpr (CHK) {  // wave-uniform: scalar division, result lives in SGPRs
+          const int k0 = kc * BK;
+          tap = k0 / g.Cin;
+          c = k0 - tap * g.Cin + kq;
+        } else {
+          tap = k / g.Cin;
+          c = k - tap * g.Cin;
+        }
+        if constexpr (AM == A_KC_CONV) {
+          dy = tap / g.kw;
+          dx = tap - dy * g.kw;
+        } else {
+          dy = -(tap >> 1);
+          dx = -(tap & 1);
+        }
         off = ((long long)dy * g.W + dx) * g.Cin + c;
       }
 #pragma unroll
@@ -248,8 +262,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
         if constexpr (BMODE == B_KS_PLAIN) {
           src += (long long)kk * g.ldb + n;
         } else if constexpr (BMODE == B_KS_TAPFLIP || BMODE == B_KS_TAPCLS) {
-          const int kks = ok ? kk : 0;
-          const int tapi = kks / g.b_Cred, cr = kks - tapi * g.b_Cred;
+          int tapi, cr;
+          if constexpr (CHK) {
+            const int k0 = kc * BK;
+            tapi = k0 / g.b_Cred;
+            cr = kk - tapi * g.b_Cred;
+          } else {
+            const int kks = ok ? kk : 0;
+            tapi = kks / g.b_Cred;
+            cr = kks - tapi * g.b_Cred;
+          }
           int tap;
           if constexpr (BMODE == B_KS_TAPFLIP) {
             tap = g.b_taps - 1 - tapi;
@@ -304,70 +326,108 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[ANR], rb[BNR];
-  unsigned ma = 0u, mb = 0u;
-  if (kc_begin < kc_end) {
-    load_A(kc_begin, ra, ma);
-    load_B(kc_begin, rb, mb);
-    store_A(0, ra, ma);
-    store_B(0, rb, mb);
-  }
-  __syncthreads();
+  // Software pipeline: two register stages + two LDS buffers, prefetch distance 2.
+  //   iteration k: issue loads(k+2) -> stage[k&1]; MFMAs on buf[k&1]; store stage[(k+1)&1] (= chunk k+1, issued one
+  //   iteration ago) -> buf[(k+1)&1]; lgkmcnt(0) + raw s_barrier (VMEM stays in flight across the barrier).
+  // A global load therefore has ~2 MFMA phases (~3.5 us) to land. The prefetch index is clamped instead of
+  // branching so every iteration is one basic block; loads are pinned into the first quarter of the MFMAs.
+  float4 ra0[ANR], rb0[BNR], ra1[ANR], rb1[BNR];
+  unsigned ma0 = 0u, mb0 = 0u, ma1 = 0u, mb1 = 0u;
+  const int kc_last = kc_end - 1;
 
-  int buf = 0;
-  for (int kc = kc_begin; kc < kc_end; ++kc) {
-    const bool more = kc + 1 < kc_end;
-    if (more) {
-      load_A(kc + 1, ra, ma);
-      load_B(kc + 1, rb, mb);
-    }
-    const float* Sa = As + buf * A_TILE;
-    const float* Sb = Bs + buf * B_TILE;
+  // fragment (operand) registers are double-buffered: quarter q+1's LDS reads are issued before quarter q's MFMAs
+  auto frag_load = [&](int q, const float* Sa, const float* Sb, float4 (&af)[TM], float4 (&bf)[TN]) {
+    const int k4 = 4 * (2 * q + lh);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k4 = 4 * (2 * q + lh);
-      float4 af[TM], bf[TN];
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        const int row = wr * WM + tm * 32 + li;
-        if constexpr (!A_KS) {
-          af[tm] = *reinterpret_cast<const float4*>(Sa + row * LDK + k4);
-        } else {
-          af[tm].x = Sa[(k4 + 0) * BM + row];
-          af[tm].y = Sa[(k4 + 1) * BM + row];
-          af[tm].z = Sa[(k4 + 2) * BM + row];
-          af[tm].w = Sa[(k4 + 3) * BM + row];
-        }
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = wr * WM + tm * 32 + li;
+      if constexpr (!A_KS) {
+        af[tm] = *reinterpret_cast<const float4*>(Sa + row * LDK + k4);
+      } else {
+        af[tm].x = Sa[(k4 + 0) * BM + row];
+        af[tm].y = Sa[(k4 + 1) * BM + row];
+        af[tm].z = Sa[(k4 + 2) * BM + row];
+        af[tm].w = Sa[(k4 + 3) * BM + row];
       }
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int row = wc * WN + tn * 32 + li;
+      if constexpr (!B_KS) {
+        bf[tn] = *reinterpret_cast<const float4*>(Sb + row * LDK + k4);
+      } else {
+        bf[tn].x = Sb[(k4 + 0) * BN + row];
+        bf[tn].y = Sb[(k4 + 1) * BN + row];
+        bf[tn].z = Sb[(k4 + 2) * BN + row];
+        bf[tn].w = Sb[(k4 + 3) * BN + row];
+      }
+    }
+  };
+  auto frag_mfma = [&](const float4 (&af)[TM], const float4 (&bf)[TN]) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        const int row = wc * WN + tn * 32 + li;
-        if constexpr (!B_KS) {
-          bf[tn] = *reinterpret_cast<const float4*>(Sb + row * LDK + k4);
-        } else {
-          bf[tn].x = Sb[(k4 + 0) * BN + row];
-          bf[tn].y = Sb[(k4 + 1) * BN + row];
-          bf[tn].z = Sb[(k4 + 2) * BN + row];
-          bf[tn].w = Sb[(k4 + 3) * BN + row];
-        }
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].x, bf[tn].x, acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].y, bf[tn].y, acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].z, bf[tn].z, acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].w, bf[tn].w, acc[tm][tn], 0, 0, 0);
       }
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].x, bf[tn].x, acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].y, bf[tn].y, acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].z, bf[tn].z, acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].w, bf[tn].w, acc[tm][tn], 0, 0, 0);
-        }
-    }
-    if (more) {
-      store_A(buf ^ 1, ra, ma);
-      store_B(buf ^ 1, rb, mb);
-    }
-    __syncthreads();
-    buf ^= 1;
+  };
+  float4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+
+  // one pipeline iteration; LD* = stage receiving chunk kc+2, ST* = stage holding chunk kc+1.
+  // On entry (fa0, fb0) hold quarter 0 of chunk kc; on exit they hold quarter 0 of chunk kc+1.
+  auto iteration = [&](int kc, int buf, float4 (&lda)[ANR], float4 (&ldb)[BNR], unsigned& lma, unsigned& lmb,
+                       const float4 (&sta)[ANR], const float4 (&stb)[BNR], unsigned sma, unsigned smb) {
+    const int k2 = kc + 2 < kc_end ? kc + 2 : kc_last;  // clamped: tail iterations re-load the last chunk (unused)
+    load_A(k2, lda, lma);
+    load_B(k2, ldb, lmb);
+    const float* Sa = As + buf * A_TILE;
+    const float* Sb = Bs + buf * B_TILE;
+    frag_load(1, Sa, Sb, fa1, fb1);
+    frag_mfma(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued before the remaining 3/4 of the MFMAs
+    frag_load(2, Sa, Sb, fa0, fb0);
+    frag_mfma(fa1, fb1);
+    frag_load(3, Sa, Sb, fa1, fb1);
+    store_A(buf ^ 1, sta, sma);
+    store_B(buf ^ 1, stb, smb);
+    frag_mfma(fa0, fb0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS traffic is done; VMEM is NOT drained
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // quarter 3's MFMAs run after the barrier and cover the latency of the next chunk's first fragment reads
+    frag_load(0, As + (buf ^ 1) * A_TILE, Bs + (buf ^ 1) * B_TILE, fa0, fb0);
+    frag_mfma(fa1, fb1);
+  };
+
+  // Two waves share each SIMD (2 blocks/CU) and run the same program: left alone they fall into lockstep and do
+  // their non-MFMA phases together, leaving the matrix pipe idle. A static priority for one of the two
+  // (hardware wave slot parity, wave-uniform scalar read) makes one stream the "owner" of the pipe and the other
+  // the gap filler (MI355X_MICROARCH §Two waves per SIMD, item 4). Speed only, never correctness.
+  if (g.prio_mode) {
+    const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | (0 << 6) | 4);  // HW_REG_HW_ID[3:0] = wave slot
+    if (__builtin_amdgcn_readfirstlane(hw_id) & 1u) __builtin_amdgcn_s_setprio(1);
   }
+  if (kc_begin < kc_end) {
+    load_A(kc_begin, ra0, ma0);
+    load_B(kc_begin, rb0, mb0);
+    store_A(0, ra0, ma0);
+    store_B(0, rb0, mb0);
+    const int k1 = kc_begin + 1 < kc_end ? kc_begin + 1 : kc_last;
+    load_A(k1, ra1, ma1);
+    load_B(k1, rb1, mb1);
+  }
+  __syncthreads();
+  frag_load(0, As, Bs, fa0, fb0);
+
+  int kc = kc_begin;
+  for (; kc + 1 < kc_end; kc += 2) {
+    iteration(kc, 0, ra0, rb0, ma0, mb0, ra1, rb1, ma1, mb1);
+    iteration(kc + 1, 1, ra1, rb1, ma1, mb1, ra0, rb0, ma0, mb0);
+  }
+  if (kc < kc_end) iteration(kc, 0, ra0, rb0, ma0, mb0, ra1, rb1, ma1, mb1);
 
   // ------------------------------------------------------------------ epilogue
   // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -428,7 +488,7 @@ __global__ void splitk_reduce_kernel(const GArgs g) {
 }
 
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, bool FAST>
+template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, int FAST>
 int launch_cfg2(GArgs g, int classes, hipStream_t stream) {
   constexpr size_t lds = 2u * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
@@ -439,7 +499,19 @@ int launch_cfg2(GArgs g, int classes, hipStream_t stream) {
   }
   const int tiles_m = fl::cdiv(g.M, BM);
   g.tiles_n = fl::cdiv(g.N, BN);
+  {
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("FL_GEMM_PRIO"); prio = e ? atoi(e) : 1; }
+    g.prio_mode = prio;
+  }
   dim3 grid((unsigned)(tiles_m * g.tiles_n), (unsigned)classes, (unsigned)(g.splitk > 1 ? g.splitk : 1));
+  static int lds_pad = -1;  // experiment knob: extra dynamic LDS to lower the number of resident blocks per CU
+  if (lds_pad < 0) { const char* e = getenv("FL_GEMM_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
+  if (lds_pad > 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + lds_pad);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds + lds_pad, stream, g);
+    return fl::check_launch("gemm_kernel");
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
   return fl::check_launch("gemm_kernel");
 }
@@ -450,8 +522,12 @@ int launch_cfg(GArgs g, int classes, hipStream_t stream) {
   if (AM != A_KS_PLAIN || BMODE == B_KC_PLAIN) fast = fast && (g.K % 4 == 0);  // a K-contiguous operand exists
   if (AM == A_KS_PLAIN) fast = fast && (g.M % 4 == 0);
   if (BMODE != B_KC_PLAIN) fast = fast && (g.N % 4 == 0);
-  if (fast) return launch_cfg2<BM, BN, WGM, WGN, AM, BMODE, true>(g, classes, stream);
-  return launch_cfg2<BM, BN, WGM, WGN, AM, BMODE, false>(g, classes, stream);
+  if constexpr (AM == A_KC_CONV || AM == A_KC_TCONV) {
+    const bool chunked = (g.Cin % BK == 0) && (BMODE == B_KC_PLAIN || g.b_Cred % BK == 0);
+    if (fast && chunked) return launch_cfg2<BM, BN, WGM, WGN, AM, BMODE, 2>(g, classes, stream);
+  }
+  if (fast) return launch_cfg2<BM, BN, WGM, WGN, AM, BMODE, 1>(g, classes, stream);
+  return launch_cfg2<BM, BN, WGM, WGN, AM, BMODE, 0>(g, classes, stream);
 }
 
 // tile-shape + split-K policy. `classes` = 4 for transposed conv, else 1.
