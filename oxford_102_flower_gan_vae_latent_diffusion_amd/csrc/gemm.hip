@@ -24,6 +24,9 @@
 #include "fl_common.h"
 #include <cstring>
 #include <cstdlib>
+#ifndef FL_ABLATE
+#define FL_ABLATE 0
+#endif
 
 namespace {
 
@@ -381,8 +384,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
   auto iteration = [&](int kc, int buf, float4 (&lda)[ANR], float4 (&ldb)[BNR], unsigned& lma, unsigned& lmb,
                        const float4 (&sta)[ANR], const float4 (&stb)[BNR], unsigned sma, unsigned smb) {
     const int k2 = kc + 2 < kc_end ? kc + 2 : kc_last;  // clamped: tail iterations re-load the last chunk (unused)
+#if !(FL_ABLATE & 1)
     load_A(k2, lda, lma);
     load_B(k2, ldb, lmb);
+#endif
     const float* Sa = As + buf * A_TILE;
     const float* Sb = Bs + buf * B_TILE;
     frag_load(1, Sa, Sb, fa1, fb1);
@@ -391,11 +396,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
     frag_load(2, Sa, Sb, fa0, fb0);
     frag_mfma(fa1, fb1);
     frag_load(3, Sa, Sb, fa1, fb1);
+#if !(FL_ABLATE & 2)
     store_A(buf ^ 1, sta, sma);
     store_B(buf ^ 1, stb, smb);
+#endif
     frag_mfma(fa0, fb0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS traffic is done; VMEM is NOT drained
+#if !(FL_ABLATE & 4)
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
     // quarter 3's MFMAs run after the barrier and cover the latency of the next chunk's first fragment reads
     frag_load(0, As + (buf ^ 1) * A_TILE, Bs + (buf ^ 1) * B_TILE, fa0, fb0);

@@ -12,7 +12,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "flowers_hip.h")
-LIB_PATH = os.path.join(_HERE, "libflowers_hip.so")
+LIB_PATH = os.environ.get("FL_LIB_PATH", os.path.join(_HERE, "libflowers_hip.so"))  # override: timing-only ablation builds
 
 _CTYPES = {
     "int": ctypes.c_int,

@@ -1,0 +1,279 @@
+"""VAE-GAN half of the surface on the GPU: backward chains vs torch autograd on the CPU oracle (fp64), the
+Discriminator / VGG paths vs golden vectors from the reference, and the fused VAE-GAN step vs two iterations of
+the reference's own train_autoencoder loop."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import procedural_init as pinit  # noqa: E402
+from oracle import v2_oracle as O  # noqa: E402
+from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M  # noqa: E402
+from oxford_102_flower_gan_vae_latent_diffusion_amd import steps  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, name + ".npz")).items()}
+
+
+def close(a, b, tol, what=""):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+    err = (a - b).abs().max().item()
+    ref = max(1e-3, b.abs().max().item())
+    assert err <= tol * ref, "%s: max err %.3e (ref max %.3e)" % (what, err, ref)
+
+
+def close_adam(a, b, lr, what="", frac=0.03):
+    """Post-Adam parameters: the first Adam steps move every weight by ~lr*sign(g), so an element whose true gradient
+    is ~0 can legitimately differ by up to 2*lr per step taken. Require: almost all elements agree to a fraction
+    of lr, and none is off by more than the sign-flip bound."""
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, what
+    err = (a - b).abs()
+    assert err.max().item() <= 4.2 * lr + 1e-7, "%s: max err %.3e exceeds the Adam sign-flip bound" % (what, err.max().item())
+    bad = (err > 0.25 * lr).double().mean().item()
+    assert bad <= frac, "%s: %.1f%% of the elements differ by more than lr/4" % (what, 100 * bad)
+
+
+def seeded(module, seed):
+    module.load_state_dict(pinit.procedural_state_dict(module.state_dict(), seed))
+    return module
+
+
+def sd64(module, prefix=""):
+    return {k: v.detach().cpu().double() for k, v in module.state_dict().items()}
+
+
+def grads_close(module, sdg, tol, prefix=""):
+    for n, p in module.named_parameters():
+        ref = sdg[prefix + n].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, "missing grad " + n
+        if ref.abs().max().item() < 1e-6:  # analytically-zero gradients (e.g. a bias feeding an instance norm)
+            assert p.grad.abs().max().item() < 1e-4, n
+            continue
+        close(p.grad, ref, tol, "grad " + n)
+
+
+def test_resblock_backward(dev):
+    ae = seeded(M.SimpleAutoencoder(), 42).to(dev)
+    rb = ae.encoder.res1
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd64(rb).items()}
+    g = torch.Generator().manual_seed(1)
+    x, dy = torch.randn(2, 128, 8, 8, generator=g), torch.randn(2, 128, 8, 8, generator=g)
+    xr = x.double().requires_grad_(True)
+    O.residual_block(sd, "", xr).backward(dy.double())
+    xd = x.to(dev).requires_grad_(True)
+    out = rb(xd)
+    out.backward(dy.to(dev))
+    close(xd.grad, xr.grad, 3e-4, "dx")
+    grads_close(rb, sd, 3e-4)
+
+
+def test_standalone_attention_backward(dev):
+    ae = seeded(M.SimpleAutoencoder(), 42).to(dev)
+    rb = ae.encoder.res2
+    g = torch.Generator().manual_seed(2)
+    x, dy = torch.randn(2, 256, 8, 8, generator=g), torch.randn(2, 256, 8, 8, generator=g)
+    for name, mod, fn in (("ca", rb.ca, O.ca_layer), ("sa", rb.sa, O.spatial_attention), ("ln", rb.ln1, O.layernorm2d)):
+        sd = {k: v.clone().requires_grad_(True) for k, v in sd64(mod).items()}
+        xr = x.double().requires_grad_(True)
+        fn(sd, "", xr).backward(dy.double())
+        xd = x.to(dev).requires_grad_(True)
+        mod.zero_grad()
+        mod(xd).backward(dy.to(dev))
+        close(xd.grad, xr.grad, 3e-4, name + " dx")
+        grads_close(mod, sd, 3e-4)
+
+
+def test_autoencoder_backward_all_terms(dev):
+    """recon + KL + classifier CE + centre loss through encoder, reparameterize, decoder, classifier."""
+    B = 2
+    ae = seeded(M.SimpleAutoencoder(), 42).to(dev).train()
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd64(ae).items()}
+    g = torch.Generator().manual_seed(3)
+    data, eps = torch.rand(B, 3, 64, 64, generator=g), torch.randn(B, 256, generator=g)
+    labels = torch.tensor([5, 77])
+    m1 = (torch.rand(B, 512, generator=g) > 0.3).float() / 0.7
+    m2 = (torch.rand(B, 256, generator=g) > 0.2).float() / 0.8
+    recon, mu, logvar, z = O.autoencoder_forward(sd, data.double(), eps.double())
+    loss = (O.euclidean_distance_loss(recon, data.double()) + 0.05 * O.kl_divergence(mu, logvar)
+            + 0.1 * F.cross_entropy(O.classify(sd, z, m1.double(), m2.double()), labels)
+            + 0.05 * O.center_loss(sd["class_centers"].detach(), z, labels))
+    loss.backward()
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import engine_bwd
+    r, mu_d, lv_d, z_d = ae(data.to(dev), eps=eps.to(dev))
+    close(r, recon, 2e-4, "recon")
+    logits = engine_bwd.classify(ae, z_d, (m1.to(dev), m2.to(dev)))
+    ce_in = logits.float()
+    l = (M.euclidean_distance_loss(r, data.to(dev)) + 0.05 * ae.kl_divergence(mu_d, lv_d)
+         + 0.1 * _ce(ce_in, labels.to(dev)) + 0.05 * ae.compute_center_loss(z_d, labels.to(dev)))
+    close(l, loss, 5e-5, "loss")
+    l.backward()
+    for n, p in ae.named_parameters():
+        ref = sd[n].grad
+        assert p.grad is not None, n
+        close(p.grad, ref, 1e-3, "grad " + n)
+
+
+class _CEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
+        loss, probs = ops.cross_entropy_fwd(logits.contiguous(), labels)
+        ctx.save_for_backward(probs, labels)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
+        probs, labels = ctx.saved_tensors
+        return ops.cross_entropy_bwd(probs, labels, 1.0, g.contiguous().view(1)), None
+
+
+def _ce(logits, labels):
+    return _CEFn.apply(logits, labels)
+
+
+def test_discriminator_vs_reference_and_backward(dev):
+    f = load("discriminator")
+    D = seeded(M.Discriminator64(), 43).to(dev).train()
+    sd0 = sd64(D)
+    with torch.no_grad():
+        close(D(f["x"].to(dev)), f["d_train"], 5e-5, "D train")
+    for k, v in D.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            close(v, f[k.replace(".", "__")], 2e-5, k)
+    D.eval()
+    with torch.no_grad():
+        close(D(f["x"].to(dev)), f["d_eval"], 5e-5, "D eval")
+    # backward (train mode, batch statistics) vs oracle autograd, incl. the input gradient
+    D = seeded(M.Discriminator64(), 43).to(dev).train()
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd0.items()}
+    xr = f["x"].double().requires_grad_(True)
+    out, _ = O.discriminator_forward(sd, xr, True)
+    F.binary_cross_entropy(out, torch.ones_like(out)).backward()
+    xd = f["x"].to(dev).requires_grad_(True)
+    p = D(xd)
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
+    l = _bce(p, 1.0)
+    l.backward()
+    close(xd.grad, xr.grad, 5e-4, "D dx")
+    grads_close(D, sd, 5e-4)
+
+
+class _BCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, target):
+        from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
+        ctx.save_for_backward(p)
+        ctx.t = target
+        return ops.bce_fwd(p.contiguous(), target).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
+        (p,) = ctx.saved_tensors
+        return ops.bce_bwd(p.contiguous(), ctx.t, 1.0, g.contiguous().view(1)), None
+
+
+def _bce(p, t):
+    return _BCEFn.apply(p, t)
+
+
+def vgg_module(dev):
+    sd = pinit.procedural_state_dict(pinit.vgg16_features16_shapes(""), 7)
+    return M.VGGPerceptualLoss(dev, state_dict=sd)
+
+
+def test_vgg_vs_reference_and_input_gradient(dev):
+    f = load("vgg")
+    vgg = vgg_module(dev)
+    with torch.no_grad():
+        close(vgg(f["x"].to(dev), f["y"].to(dev)), f["loss"], 5e-5, "vgg loss")
+    sd = {"feature_extractor." + k: v.double() for k, v in pinit.procedural_state_dict(pinit.vgg16_features16_shapes(""), 7).items()}
+    xr = f["x"].double().requires_grad_(True)
+    O.vgg_perceptual_loss(sd, xr, f["y"].double()).backward()
+    xd = f["x"].to(dev).requires_grad_(True)
+    vgg(xd, f["y"].to(dev)).backward()
+    close(xd.grad, xr.grad, 5e-4, "vgg dx")
+
+
+def test_vae_gan_step_vs_reference_loop(dev):
+    """Two iterations (epoch 0 phase, OneCycleLR) of the reference's own train_autoencoder."""
+    f = load("vae_gan_loop")
+    ae = seeded(M.SimpleAutoencoder(), 42).to(dev).train()
+    D = seeded(M.Discriminator64(), 43).to(dev).train()
+    tr = steps.VAEGANTrainer(ae, D, vgg_module(dev), lr=1e-4)
+    dummy = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    sch = torch.optim.lr_scheduler.OneCycleLR(dummy, max_lr=1e-4, total_steps=2, pct_start=0.3, div_factor=25,
+                                              final_div_factor=1000)
+    hist = {k: [] for k in ("total", "recon", "perceptual", "kl", "cls", "center", "adv")}
+    for i in range(2):
+        lr = dummy.param_groups[0]["lr"]
+        out = tr.step(f["data%d" % i].to(dev), f["labels%d" % i].to(dev), epoch=0, num_epochs=1, lr=lr,
+                      reparam_eps=f["reparam_eps%d" % i].to(dev))
+        for k in hist:
+            hist[k].append(float(out[k]))
+        dummy.step()
+        if i == 0:
+            sch.step()
+    for k, hk in (("total", "total"), ("recon", "recon"), ("perceptual", "perceptual"), ("kl", "kl"), ("cls", "class"),
+                  ("center", "center"), ("adv", "gan")):
+        close(np.mean(hist[k]), f["hist_" + hk], 5e-4, "loss history " + hk)
+    sd = ae.state_dict()
+    for k in [k for k in f if k.startswith("ae__")]:
+        key = k[4:].replace("__", ".")
+        close_adam(sd[key].reshape(-1)[:64], f[k], 1e-4, "post-step AE " + key, frac=0.1)
+    dsd = D.state_dict()
+    for k in [k for k in f if k.startswith("d__")]:
+        key = k[3:].replace("__", ".")
+        if "running" in key:
+            close(dsd[key].reshape(-1)[:64], f[k], 1e-3, "post-step D " + key)
+        else:
+            # conv biases feeding a BatchNorm have an analytically-zero gradient: Adam moves them by rounding-noise signs
+            frac = 1.0 if key in ("model.2.bias", "model.5.bias", "model.8.bias") else 0.1
+            close_adam(dsd[key].reshape(-1)[:64], f[k], 1e-4, "post-step D " + key, frac=frac)
+
+
+def test_vae_gan_step_all_terms_vs_oracle(dev):
+    """epoch 200: all six loss terms + centre EMA, one step vs the (reference-pinned) oracle step."""
+    B = 4
+    g = torch.Generator().manual_seed(9)
+    data, labels = torch.rand(B, 3, 64, 64, generator=g), torch.randint(0, 102, (B,), generator=g)
+    eps = torch.randn(B, 256, generator=g)
+    m1 = (torch.rand(B, 512, generator=g) > 0.3).float() / 0.7
+    m2 = (torch.rand(B, 256, generator=g) > 0.2).float() / 0.8
+    ae = seeded(M.SimpleAutoencoder(), 42)
+    D = seeded(M.Discriminator64(), 43)
+    ae_sd = {k: v.clone() for k, v in ae.state_dict().items()}
+    d_sd = {k: v.clone() for k, v in D.state_dict().items()}
+    vgg_sd = {"feature_extractor." + k: v for k, v in pinit.procedural_state_dict(pinit.vgg16_features16_shapes(""), 7).items()}
+    ref = O.vae_gan_step(ae_sd, d_sd, vgg_sd, data, labels, eps, epoch=200, num_epochs=300, lr=1e-4, cls_masks=(m1, m2))
+    ae, D = ae.to(dev).train(), D.to(dev).train()
+    tr = steps.VAEGANTrainer(ae, D, vgg_module(dev), lr=1e-4)
+    out = tr.step(data.to(dev), labels.to(dev), epoch=200, num_epochs=300, lr=1e-4, reparam_eps=eps.to(dev),
+                  cls_masks=(m1.to(dev), m2.to(dev)))
+    for k in ("total", "recon", "perceptual", "kl", "cls", "center", "adv", "d_loss"):
+        close(out[k].reshape(()), ref["losses"][k].reshape(()), 2e-4, "loss " + k)
+    close(out["grad_norm"].reshape(()), ref["grad_norm"].reshape(()), 1e-3, "grad norm")
+    close(out["recon_x"], ref["recon_x"], 3e-4, "recon")
+    sd = ae.state_dict()
+    for k in ("encoder.initial_conv.0.weight", "encoder.res2.conv1.weight", "encoder.fc_mu.0.weight", "decoder.fc.3.weight",
+              "decoder.up2.0.weight", "decoder.final_conv.3.weight", "classifier.4.weight", "classifier.8.bias",
+              "encoder.res1.sa.conv.weight", "decoder.res3.ca.conv_du.0.weight", "decoder.up1.1.weight"):
+        close_adam(sd[k], ref["new_ae_sd"][k], 1e-4, "post-step " + k)
+    close(ae.class_centers, ref["centers"], 1e-5, "centres")
+    dsd = D.state_dict()
+    for k in ("model.0.weight", "model.5.weight", "model.6.weight", "model.11.weight"):
+        close_adam(dsd[k], ref["new_d_sd"][k], 1e-4, "post-step D " + k)
+    close(dsd["model.9.running_var"], ref["new_d_sd"]["model.9.running_var"], 1e-3, "running var")
