@@ -219,7 +219,10 @@ def main():
                 "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": r["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, averaged over the 9
+                # launches at B=256; profiles/r01_conv_kernel_pmc.md). Not re-measured live: PMC needs the profiler.
+                "traffic": 4.08e8 if B == 256 else None,
+                "algorithmic_bytes_per_launch": 1.86e8 if B == 256 else None,
                 "avg_launch_ms": r["avg_ms"],
                 "algorithmic_gflop_per_launch": r["flop_per_launch"] / 1e9,
                 "launches_per_step": r["launches"],

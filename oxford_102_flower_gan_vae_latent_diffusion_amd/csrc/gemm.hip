@@ -126,7 +126,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
   const int wr = wid / WGN, wc = wid % WGN;
   const int li = lane & 31, lh = lane >> 5;
 
-  const int tile = blockIdx.x;
+  // XCD-aware tile order: hardware deals consecutive block ids round-robin over the 8 XCDs (private L2s), so remap
+  // id -> tile such that each XCD owns a contiguous range of tiles (the N-tiles of an M-tile and neighbouring
+  // M-tiles, which share conv halo rows, then hit the same L2). Bijective for any grid size. Speed only.
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
   const int tile_m0 = (tile / g.tiles_n) * BM;
   const int tile_n0 = (tile % g.tiles_n) * BN;
   const int cls = blockIdx.y;  // sub-pixel class (transposed conv only)

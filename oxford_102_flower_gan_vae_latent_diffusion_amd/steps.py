@@ -115,6 +115,22 @@ class FusedAdam:
         fp.bump()
 
 
+def allreduce_grads(fp, world_size, group=None):
+    """The ONE collective of a data-parallel step: sum the flat active-gradient buffer over ranks (RCCL over xGMI
+    when the buffer lives on a GPU, gloo in the CPU tests). The 1/world factor is applied by the caller (folded into
+    the clip/Adam kernel), so that mean-of-shard-gradients == global-batch gradient (the loss is a batch mean,
+    v2:298)."""
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(fp.grad[:fp.n_active], group=group)
+    return fp.grad[:fp.n_active]
+
+
+def shard_seed(base, rank):
+    """Per-rank RNG seed offset (t / eps / dropout draws are independent per rank)."""
+    return int(base) + 97 * int(rank)
+
+
 class DDPMTrainer:
     """Latent-DDPM training step (configs 3/4 of BASELINE.json)."""
 
@@ -163,9 +179,7 @@ class DDPMTrainer:
         self.eps_theta = eps_theta
 
     def allreduce(self):
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.fp.grad[:self.fp.n_active], group=self.pg)
+        allreduce_grads(self.fp, self.world, self.pg)
 
     @torch.no_grad()
     def update(self):
