@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE metric: 256)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="do not pipeline encoder(k+1) under the denoiser update(k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -112,6 +113,10 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    # rehearsal knobs (1-GPU boxes): FL_DIST_BACKEND=gloo + FL_SHARE_DEVICE=1 run all ranks on cuda:0 over gloo
+    backend = os.environ.get("FL_DIST_BACKEND", "nccl")
+    if os.environ.get("FL_SHARE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
@@ -119,7 +124,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M
@@ -147,11 +155,18 @@ def main():
 
     log("models + synthetic batches resident in HBM (B=%d per GPU)" % B)
     use_graph = not a.no_graph
-    if use_graph:
+    overlap = use_graph and not a.no_overlap
+    if overlap:
+        tr.capture_pipelined(sdata, slabels)
+        tr.prime_pipeline(batches[0], labels[0])
+        log("hipGraphs captured (encoder || denoiser pipeline)")
+    elif use_graph:
         tr.capture(sdata, slabels)
         log("hipGraph captured")
 
     def one_step(i):
+        if overlap:  # step i trains on batch i (already encoded) while batch i+1 is being encoded
+            return tr.replay_pipelined(batches[(i + 1) % nb], labels[(i + 1) % nb])
         if use_graph:
             sdata.copy_(batches[i % nb])
             slabels.copy_(labels[i % nb])
@@ -172,7 +187,9 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(a.steps):
-        loss = one_step(i)
+        loss = one_step(a.warmup + i)
+    if overlap:
+        tr.sync_pipeline()
     torch.cuda.synchronize(dev)
     barrier()
     dt = time.perf_counter() - t0
@@ -205,6 +222,7 @@ def main():
             "global_batch": world * B,
             "parallelism": "dp%d" % world,
             "hipgraph": use_graph,
+            "encoder_denoiser_overlap": overlap,
             "loss": final_loss,
         },
     }

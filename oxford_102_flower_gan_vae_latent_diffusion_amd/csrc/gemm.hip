@@ -27,6 +27,12 @@
 #ifndef FL_ABLATE
 #define FL_ABLATE 0
 #endif
+#ifndef FL_USE_DMA
+#define FL_USE_DMA 0  // direct-to-LDS staging: correct, measured 3% slower than register staging on gfx950 (r01)
+#endif
+#ifndef FL_MFMA_ROT
+#define FL_MFMA_ROT 1  // issue consecutive MFMAs on different accumulators
+#endif
 
 namespace {
 
@@ -71,6 +77,9 @@ struct GArgs {
   int prio_mode;
 };
 
+// 16 zero bytes: source of out-of-bounds / padding lanes of direct-to-LDS loads
+__device__ const float4 g_zero16 = {0.f, 0.f, 0.f, 0.f};
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
@@ -87,6 +96,14 @@ __device__ __forceinline__ float4 ld4g(const float* p, int nvalid, int vec) {
 
 // FAST: branch-free predicated vector load (clamped address + select) — legal when every valid float4 is whole
 // and 16-byte aligned; otherwise the guarded (slow, branchy) form handles tails / unaligned operands.
+// one direct-to-LDS 16-byte load per lane: lds_piece is the wave-uniform 1-KiB destination
+__device__ __forceinline__ void dma16(const float* p, bool ok, float* lds_piece) {
+  const float* src = ok ? p : reinterpret_cast<const float*>(&g_zero16);
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_piece, 16, 0, 0);
+}
+
 template <bool FAST>
 __device__ __forceinline__ float4 ldsel(const float* p, bool ok, int nvalid, int vec, const float* safe) {
   if constexpr (FAST) {
@@ -116,13 +133,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
   constexpr int ANR = BM / 32, BNR = BN / 32;  // float4 per thread per chunk
   constexpr bool A_KS = (AM == A_KS_PLAIN);
   constexpr bool B_KS = (BMODE != B_KC_PLAIN);
-  constexpr int A_TILE = BM * LDK, B_TILE = BN * LDK;  // floats per buffer (KS image is smaller)
+  // PATH >= 1 stages global -> LDS directly (LDS-DMA, global_load_lds_dwordx4): no VGPR staging, no ds_write, no
+  // zero-selects. A wave-instruction writes 1 KiB contiguously (wave-uniform base + lane*16), so the K-contiguous
+  // image is UNPADDED [rows][32] with an XOR swizzle on the 16-byte chunk index applied on the SOURCE side
+  // (lane l of a piece loads logical chunk (l&7) ^ ((row>>1)&7)) and again on the fragment read; over the 16 rows
+  // of a ds_read_b128 lane group (row&1, (row>>1)&7) takes 16 distinct values -> conflict-free. K-strided images
+  // ([32][rows]) are lane-linear already. Padding / out-of-range lanes read 16 zero bytes (g_zero16).
+  constexpr bool DMA = (PATH >= 1) && (FL_USE_DMA != 0);
+  constexpr int KCS = DMA ? BK : LDK;                   // row stride (floats) of a K-contiguous image
+  constexpr int A_TILE = BM * KCS, B_TILE = BN * KCS;   // floats per buffer (the K-strided image is 32*rows <= this)
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * A_TILE;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid / WGN, wc = wid % WGN;
   const int li = lane & 31, lh = lane >> 5;
 
@@ -150,7 +175,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
 
   // ------------------------------------------------------------------ A loader state
   // KC mapping: thread -> (row = tid>>3 (+32r), 4 consecutive k at (tid&7)*4)
-  const int ld_row = tid >> 3, kq = (tid & 7) * 4;
+  // DMA: the thread's logical 16-byte chunk is XOR-swizzled by its row ((row>>1)&7 == ((lane>>4) + 4*wid) & 7)
+  const int ld_row = tid >> 3;
+  const int kq = DMA ? (((tid & 7) ^ (((lane >> 4) + 4 * wid) & 7)) * 4) : (tid & 7) * 4;
   // KS mapping for an operand of R rows: TPR = R/4 threads per k-row
   constexpr int A_TPR = BM / 4, A_RPP = 256 / A_TPR;
   constexpr int B_TPR = BN / 4, B_RPP = 256 / B_TPR;
@@ -205,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
     b_kx = tap - b_ky * g.kw;
   }
 
-  auto load_A = [&](int kc, float4 (&regs)[ANR], unsigned& mask) {
+  auto load_A = [&](int kc, float4 (&regs)[ANR], unsigned& mask, float* dst) {
     mask = 0u;
     if constexpr (!A_KS) {
       const int k = kc * BK + kq;
@@ -237,8 +264,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
         if constexpr (AM != A_KC_PLAIN) {
           ok = ok & ((unsigned)(a_iy0[r] + dy) < (unsigned)g.H) & ((unsigned)(a_ix0[r] + dx) < (unsigned)g.W);
         }
-        regs[r] = ldsel<FAST>(g.A + a_base[r] + off, ok, kleft, g.a_vec, g.A);
-        mask |= (ok ? 1u : 0u) << r;
+        if constexpr (DMA) {
+          dma16(g.A + a_base[r] + off, ok, dst + (wid * 8 + 32 * r) * BK);
+        } else {
+          regs[r] = ldsel<FAST>(g.A + a_base[r] + off, ok, kleft, g.a_vec, g.A);
+          mask |= (ok ? 1u : 0u) << r;
+        }
       }
     } else {
 #pragma unroll
@@ -246,13 +277,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
         const int kk = kc * BK + a_ks_row + p * A_RPP;
         const int m = tile_m0 + a_ks_c;
         const bool ok = (kk < g.K) & (m < g.M);
-        regs[p] = ldsel<FAST>(g.A + (long long)kk * g.lda + m, ok, g.M - m, g.a_vec, g.A);
-        mask |= (ok ? 1u : 0u) << p;
+        if constexpr (DMA) {
+          dma16(g.A + (long long)kk * g.lda + m, ok, dst + (wid * 64 + p * 256) * 4);
+        } else {
+          regs[p] = ldsel<FAST>(g.A + (long long)kk * g.lda + m, ok, g.M - m, g.a_vec, g.A);
+          mask |= (ok ? 1u : 0u) << p;
+        }
       }
     }
   };
 
-  auto load_B = [&](int kc, float4 (&regs)[BNR], unsigned& mask) {
+  auto load_B = [&](int kc, float4 (&regs)[BNR], unsigned& mask, float* dst) {
     mask = 0u;
     if constexpr (BMODE == B_KC_PLAIN) {
       const int k = kc * BK + kq;
@@ -260,8 +295,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
 #pragma unroll
       for (int r = 0; r < BNR; ++r) {
         const bool ok = b_ok[r] & (kleft > 0);
-        regs[r] = ldsel<FAST>(g.B + b_base[r] + k, ok, kleft, g.b_vec, g.B);
-        mask |= (ok ? 1u : 0u) << r;
+        if constexpr (DMA) {
+          dma16(g.B + b_base[r] + k, ok, dst + (wid * 8 + 32 * r) * BK);
+        } else {
+          regs[r] = ldsel<FAST>(g.B + b_base[r] + k, ok, kleft, g.b_vec, g.B);
+          mask |= (ok ? 1u : 0u) << r;
+        }
       }
     } else {
       const int n = tile_n0 + b_ks_c;
@@ -300,8 +339,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
           ok = ok & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
           src += (((long long)img * g.H + iy) * g.W + ix) * g.Cin + b_ci;
         }
-        regs[p] = ldsel<FAST>(src, ok, g.N - n, g.b_vec, g.B);
-        mask |= (ok ? 1u : 0u) << p;
+        if constexpr (DMA) {
+          dma16(src, ok, dst + (wid * 64 + p * 256) * 4);
+        } else {
+          regs[p] = ldsel<FAST>(src, ok, g.N - n, g.b_vec, g.B);
+          mask |= (ok ? 1u : 0u) << p;
+        }
       }
     }
   };
@@ -353,7 +396,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
     for (int tm = 0; tm < TM; ++tm) {
       const int row = wr * WM + tm * 32 + li;
       if constexpr (!A_KS) {
-        af[tm] = *reinterpret_cast<const float4*>(Sa + row * LDK + k4);
+        if constexpr (DMA) af[tm] = *reinterpret_cast<const float4*>(Sa + row * BK + (((2 * q + lh) ^ ((row >> 1) & 7)) << 2));
+        else af[tm] = *reinterpret_cast<const float4*>(Sa + row * LDK + k4);
       } else {
         af[tm].x = Sa[(k4 + 0) * BM + row];
         af[tm].y = Sa[(k4 + 1) * BM + row];
@@ -365,7 +409,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
     for (int tn = 0; tn < TN; ++tn) {
       const int row = wc * WN + tn * 32 + li;
       if constexpr (!B_KS) {
-        bf[tn] = *reinterpret_cast<const float4*>(Sb + row * LDK + k4);
+        if constexpr (DMA) bf[tn] = *reinterpret_cast<const float4*>(Sb + row * BK + (((2 * q + lh) ^ ((row >> 1) & 7)) << 2));
+        else bf[tn] = *reinterpret_cast<const float4*>(Sb + row * LDK + k4);
       } else {
         bf[tn].x = Sb[(k4 + 0) * BN + row];
         bf[tn].y = Sb[(k4 + 1) * BN + row];
@@ -375,6 +420,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
     }
   };
   auto frag_mfma = [&](const float4 (&af)[TM], const float4 (&bf)[TN]) {
+#if FL_MFMA_ROT
+#define FL_MFMA_STEP(c)                                                                                          \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)          \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].c, bf[tn].c, acc[tm][tn], 0, 0, 0);
+    FL_MFMA_STEP(x) FL_MFMA_STEP(y) FL_MFMA_STEP(z) FL_MFMA_STEP(w)
+#undef FL_MFMA_STEP
+#else
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -384,6 +436,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].z, bf[tn].z, acc[tm][tn], 0, 0, 0);
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm].w, bf[tn].w, acc[tm][tn], 0, 0, 0);
       }
+#endif
   };
   float4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
 
@@ -393,8 +446,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
                        const float4 (&sta)[ANR], const float4 (&stb)[BNR], unsigned sma, unsigned smb) {
     const int k2 = kc + 2 < kc_end ? kc + 2 : kc_last;  // clamped: tail iterations re-load the last chunk (unused)
 #if !(FL_ABLATE & 1)
-    load_A(k2, lda, lma);
-    load_B(k2, ldb, lmb);
+    load_A(k2, lda, lma, nullptr);
+    load_B(k2, ldb, lmb, nullptr);
 #endif
     const float* Sa = As + buf * A_TILE;
     const float* Sb = Bs + buf * B_TILE;
@@ -427,24 +480,72 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
     const unsigned hw_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | (0 << 6) | 4);  // HW_REG_HW_ID[3:0] = wave slot
     if (__builtin_amdgcn_readfirstlane(hw_id) & 1u) __builtin_amdgcn_s_setprio(1);
   }
-  if (kc_begin < kc_end) {
-    load_A(kc_begin, ra0, ma0);
-    load_B(kc_begin, rb0, mb0);
-    store_A(0, ra0, ma0);
-    store_B(0, rb0, mb0);
-    const int k1 = kc_begin + 1 < kc_end ? kc_begin + 1 : kc_last;
-    load_A(k1, ra1, ma1);
-    load_B(k1, rb1, mb1);
-  }
-  __syncthreads();
-  frag_load(0, As, Bs, fa0, fb0);
+  if constexpr (!DMA) {
+    if (kc_begin < kc_end) {
+      load_A(kc_begin, ra0, ma0, nullptr);
+      load_B(kc_begin, rb0, mb0, nullptr);
+      store_A(0, ra0, ma0);
+      store_B(0, rb0, mb0);
+      const int k1 = kc_begin + 1 < kc_end ? kc_begin + 1 : kc_last;
+      load_A(k1, ra1, ma1, nullptr);
+      load_B(k1, rb1, mb1, nullptr);
+    }
+    __syncthreads();
+    frag_load(0, As, Bs, fa0, fb0);
 
-  int kc = kc_begin;
-  for (; kc + 1 < kc_end; kc += 2) {
-    iteration(kc, 0, ra0, rb0, ma0, mb0, ra1, rb1, ma1, mb1);
-    iteration(kc + 1, 1, ra1, rb1, ma1, mb1, ra0, rb0, ma0, mb0);
+    int kc = kc_begin;
+    for (; kc + 1 < kc_end; kc += 2) {
+      iteration(kc, 0, ra0, rb0, ma0, mb0, ra1, rb1, ma1, mb1);
+      iteration(kc + 1, 1, ra1, rb1, ma1, mb1, ra0, rb0, ma0, mb0);
+    }
+    if (kc < kc_end) iteration(kc, 0, ra0, rb0, ma0, mb0, ra1, rb1, ma1, mb1);
+  } else {
+    // ---- direct-to-LDS pipeline: 2 LDS buffers, DMA(k+1) in flight under the MFMAs of chunk k ----
+    // hipcc waits vmcnt(0) before any ds_read that follows an LDS-DMA in program order (it cannot prove that the
+    // two buffers do not alias), so within an iteration every LDS read precedes the DMA issue: the whole chunk's
+    // fragments (4 quarters, 64 VGPRs) are read right after the barrier, overlapped with the previous chunk's
+    // last 16 MFMAs, then the DMA is issued, then the MFMAs run from registers.
+    auto issue = [&](int kc_, int buf_) {
+      unsigned dm;
+      load_A(kc_, ra0, dm, As + buf_ * A_TILE);
+      load_B(kc_, rb0, dm, Bs + buf_ * B_TILE);
+    };
+    float4 qa0[TM], qb0[TN], qa1[TM], qb1[TN], qa2[TM], qb2[TN], qa3[TM], qb3[TN];
+    if (kc_begin < kc_end) issue(kc_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    frag_load(0, As, Bs, qa0, qb0);
+    frag_load(1, As, Bs, qa1, qb1);
+    frag_load(2, As, Bs, qa2, qb2);
+    frag_load(3, As, Bs, qa3, qb3);
+    int buf = 0;
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+      const int k1 = kc + 1 < kc_end ? kc + 1 : kc_last;  // clamped: the last iteration re-stages the last chunk (unused)
+      issue(k1, buf ^ 1);  // buf^1: every read of it was retired before the previous barrier
+      frag_mfma(qa0, qb0);  // same scheduling region: address arithmetic + DMA issue interleave with 16 MFMAs
+      __builtin_amdgcn_sched_barrier(0);  // ... but the DMA is issued before the remaining MFMAs
+      frag_mfma(qa1, qb1);
+      frag_mfma(qa2, qb2);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa1[i] = qa3[i];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fb1[i] = qb3[i];
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+      __builtin_amdgcn_s_barrier();                      // ... and everyone else's
+      asm volatile("" ::: "memory");
+      const float* Sa = As + (buf ^ 1) * A_TILE;
+      const float* Sb = Bs + (buf ^ 1) * B_TILE;
+      frag_load(0, Sa, Sb, qa0, qb0);
+      frag_load(1, Sa, Sb, qa1, qb1);
+      frag_load(2, Sa, Sb, qa2, qb2);
+      frag_load(3, Sa, Sb, qa3, qb3);
+      frag_mfma(fa1, fb1);  // quarter 3 of chunk k covers the fragment reads of chunk k+1
+      __builtin_amdgcn_sched_barrier(0);
+      buf ^= 1;
+    }
   }
-  if (kc < kc_end) iteration(kc, 0, ra0, rb0, ma0, mb0, ra1, rb1, ma1, mb1);
 
   // ------------------------------------------------------------------ epilogue
   // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -507,7 +608,7 @@ __global__ void splitk_reduce_kernel(const GArgs g) {
 // ------------------------------------------------------------------------------------
 template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, int FAST>
 int launch_cfg2(GArgs g, int classes, hipStream_t stream) {
-  constexpr size_t lds = 2u * (BM + BN) * LDK * sizeof(float);
+  constexpr size_t lds = 2u * (BM + BN) * ((FAST >= 1 && FL_USE_DMA) ? BK : LDK) * sizeof(float);
   static bool attr_set = false;
   auto kern = gemm_kernel<BM, BN, WGM, WGN, AM, BMODE, FAST>;
   if (!attr_set) {

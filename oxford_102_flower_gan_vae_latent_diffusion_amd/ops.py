@@ -16,6 +16,15 @@ ACT_NONE, ACT_SWISH, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 KC, KS = 0, 1
 
 _workspaces = {}
+_ws_slot = 0
+
+
+def set_workspace_slot(slot):
+    """Scratch buffers are per (device, slot): work captured/launched on concurrently running streams must use
+    different slots (the split-K slabs / norm partials of one stream would otherwise race with the other's)."""
+    global _ws_slot
+    old, _ws_slot = _ws_slot, int(slot)
+    return old
 
 
 def _stream():
@@ -44,11 +53,12 @@ def workspace(nbytes, device=None):
     if isinstance(device, torch.device):
         device = device.index if device.index is not None else torch.cuda.current_device()
     nbytes = max(int(nbytes), 1 << 20)
+    device = (device, _ws_slot)
     ws = _workspaces.get(device)
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("workspace would grow during graph capture; run a warm-up step first")
-        ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device="cuda:%d" % device)
+        ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device="cuda:%d" % device[0])
         _workspaces[device] = ws
     return ws
 

@@ -216,6 +216,75 @@ class DDPMTrainer:
         self.g2.replay()
         return self.loss
 
+    # ---- cross-step software pipeline -------------------------------------------------------------------
+    # The frozen encoder of batch k+1 does not depend on the denoiser update of batch k (v2:1257-1259 runs under
+    # no_grad on a module that is never trained here), so the two phases run concurrently: stream E replays the
+    # encoder graph for the NEXT batch (large MFMA-bound conv kernels) while stream U replays the denoiser
+    # fwd/bwd + all-reduce + clip/AdamW for the CURRENT latents (hundreds of small latency-bound launches that
+    # leave most CUs idle). Same arithmetic, same order of parameter updates; z/labels are double-buffered.
+    def capture_pipelined(self, data, labels):
+        dev = self.dev
+        self.static_data, self.static_labels = data, labels
+        for _ in range(2):
+            self.step(data, labels)
+        self.sE, self.sU = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        torch.cuda.synchronize(dev)
+        B, L = data.shape[0], self.ae.latent_dim
+        self.z_next = torch.zeros(B, L, device=dev)
+        self.z_in = torch.zeros(B, L, device=dev)
+        self.lab_next, self.lab_in = labels.clone(), labels.clone()
+        old = ops.set_workspace_slot(1)           # encoder graph: its own scratch (runs concurrently with U)
+        self.encode(data)                         # size slot-1 workspace outside capture
+        torch.cuda.synchronize(dev)
+        self.gE = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gE):
+            self.z_out = self.encode(self.static_data)
+        ops.set_workspace_slot(old)
+        self.gU = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gU):
+            self.fwd_bwd(self.z_in, self.lab_in)
+        self.gO = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gO):
+            self.update()
+        self.ev_enc, self.ev_used = torch.cuda.Event(), torch.cuda.Event()
+        self._primed = False
+
+    def _launch_encoder(self, data, labels):
+        cur = torch.cuda.current_stream(self.dev)
+        self.sE.wait_stream(cur)
+        with torch.cuda.stream(self.sE):
+            self.static_data.copy_(data, non_blocking=True)
+            self.gE.replay()
+            if self._primed:
+                self.sE.wait_event(self.ev_used)   # z_next / lab_next of the previous batch have been consumed
+            self.z_next.copy_(self.z_out, non_blocking=True)
+            self.lab_next.copy_(labels, non_blocking=True)
+            self.ev_enc.record(self.sE)
+
+    def prime_pipeline(self, data, labels):
+        """encode the first batch (before the timed region)."""
+        self._launch_encoder(data, labels)
+        self._primed = True
+
+    def replay_pipelined(self, next_data, next_labels):
+        """one step: denoiser update on the latents encoded by the previous call, while `next_data` is encoded."""
+        with torch.cuda.stream(self.sU):
+            self.sU.wait_event(self.ev_enc)
+            self.z_in.copy_(self.z_next, non_blocking=True)
+            self.lab_in.copy_(self.lab_next, non_blocking=True)
+            self.ev_used.record(self.sU)
+        self._launch_encoder(next_data, next_labels)
+        with torch.cuda.stream(self.sU):
+            self.gU.replay()
+            self.allreduce()
+            self.gO.replay()
+        return self.loss
+
+    def sync_pipeline(self):
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_stream(self.sE)
+        cur.wait_stream(self.sU)
+
 
 def loss_phase(epoch):
     """Loss gating of v2:1072-1087 -> (kl_factor, cls_factor, center_factor)."""

@@ -203,3 +203,47 @@ def test_sampler_graph_equals_eager_and_oracle(dev, unet):
     s = d2.sample((B, 256), dev, c)
     assert s.shape == (B, 256) and torch.isfinite(s).all()
     assert d2.p_sample_loop.__func__ is d2.sample.__func__
+
+
+def test_pipelined_trainer_equals_plain_trainer(dev):
+    """encoder(k+1) || denoiser-update(k) on two streams must give exactly the plain step's parameters."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
+    B, nsteps = 16, 4
+    batches, labels = [], []
+    for i in range(nsteps + 1):
+        d = torch.empty(B, 3, 64, 64, device=dev)
+        ops.philox_fill(d, seed=500 + i, mode=2)
+        l = torch.empty(B, dtype=torch.int64, device=dev)
+        ops.philox_randint(l, seed=600 + i, hi=102)
+        batches.append(d)
+        labels.append(l)
+
+    def make():
+        ae = seeded(M.SimpleAutoencoder(), 42).to(dev).eval()
+        un = seeded(M.ConditionalUNet(), 44).to(dev).train()
+        tr = steps.DDPMTrainer(ae, un, lr=1e-3)
+        for r, s in ((ae.rng, 1), (un.rng, 2), (tr.diffusion.rng, 3)):
+            r.manual_seed(s)
+        return ae, un, tr
+
+    ae, un, tr = make()
+    losses_a = [float(tr.step(batches[i], labels[i])) for i in range(nsteps)]
+    pa = tr.fp.flat.clone()
+
+    ae, un, tr = make()
+    sd0 = {k: v.clone() for k, v in un.state_dict().items()}
+    tr.capture_pipelined(batches[0].clone(), labels[0].clone())
+    # capture ran warm-up steps: restore weights, optimizer and RNG state
+    un.load_state_dict(sd0)
+    tr.opt.m.zero_(); tr.opt.v.zero_(); tr.opt.step_count.zero_()
+    for r, s in ((ae.rng, 1), (un.rng, 2), (tr.diffusion.rng, 3)):
+        r.manual_seed(s)
+    tr.prime_pipeline(batches[0], labels[0])
+    losses_b = []
+    for i in range(nsteps):
+        l = tr.replay_pipelined(batches[i + 1], labels[i + 1])
+        tr.sync_pipeline()
+        torch.cuda.synchronize()
+        losses_b.append(float(l))
+    close(torch.tensor(losses_b), torch.tensor(losses_a), 1e-6, "loss sequence")
+    assert torch.equal(tr.fp.flat, pa), "pipelined parameters differ from the plain step"
