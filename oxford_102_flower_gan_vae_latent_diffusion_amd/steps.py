@@ -316,8 +316,24 @@ class VAEGANTrainer:
         self.d_opt = FusedAdam(self.dfp, 1e-4, betas=(0.5, 0.999), weight_decay=0.0, decoupled=False)  # v2:1028
         self.lam = (lambda_cls, lambda_center, lambda_vgg, lambda_gan)
         self.terms = torch.zeros(6, dtype=torch.float32, device=dev)
-        self.weights = torch.zeros(6, dtype=torch.float32, device=dev)
+        self._wcache = {}
         self.out = {}
+        self.graph = None
+
+    def capture(self, data, labels, epoch=0, num_epochs=300):
+        """Capture the whole step (one loss phase = one graph) as a hipGraph; `data`/`labels` become the static input
+        buffers. replay() after copying a new batch into them."""
+        self.static_data, self.static_labels = data, labels
+        for _ in range(2):
+            self.step(data, labels, epoch=epoch, num_epochs=num_epochs)
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.step(self.static_data, self.static_labels, epoch=epoch, num_epochs=num_epochs)
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
 
     @torch.no_grad()
     def step(self, data, labels, epoch=0, num_epochs=300, lr=None, reparam_eps=None, cls_masks=(None, None)):
@@ -374,8 +390,12 @@ class VAEGANTrainer:
         # ---- device-side loss balancing (v2:1107-1125) ----
         for i, tsr in enumerate((recon_loss, percep, kl, adv, ce, cen)):
             ops.axpby(1.0, tsr, out=self.terms[i:i + 1])
-        self.weights.copy_(torch.tensor([1.0, l_vgg, klw * klf, l_gan, l_cls * clsf, l_cen * cenf]))
-        coeff, total = ops.balance_losses(self.terms, self.weights)
+        wkey = (1.0, l_vgg, klw * klf, l_gan, l_cls * clsf, l_cen * cenf)
+        w = self._wcache.get(wkey)
+        if w is None:  # one H2D copy per distinct (epoch-dependent) weight vector, never inside the step proper
+            w = torch.tensor(wkey, dtype=torch.float32, device=self.dev)
+            self._wcache[wkey] = w
+        coeff, total = ops.balance_losses(self.terms, w)
         # ---- backward of total_loss w.r.t. the autoencoder (v2:1127) ----
         drecon = ops.euclid_loss_bwd(recon, data, rn, 1.0, coeff[0:1])
         dfx = ops.euclid_loss_bwd(fx, fy, pn, 1.0, coeff[1:2])
