@@ -373,7 +373,6 @@ int fl_advance_offset(int64_t* dev_offset, int64_t delta, fl_stream_t stream) {
   hipLaunchKernelGGL(advance_offset_kernel, dim3(1), dim3(64), 0, ST(stream), (long long*)dev_offset, (long long)delta);
   return fl::check_launch("advance_offset");
 }
-size_t fl_colsum_workspace_bytes(int M, int N) { return (size_t)fl::cdiv(M, 32) * N * sizeof(float); }
 int fl_gated_add(const float* a, const float* b, const float* w, float* out, int64_t n, fl_stream_t stream) {
   if (!n) return FL_OK;
   hipLaunchKernelGGL(gated_add_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), a, b, w, out, (long long)n);
@@ -383,14 +382,21 @@ int fl_gate_grad(const float* x, const float* y, const float* w, float* out, int
   hipLaunchKernelGGL(gate_grad_kernel, dim3(1), dim3(1024), 0, ST(stream), x, y, w, out, (long long)n);
   return fl::check_launch("gate_grad");
 }
+// rows per slab: at least 32, and few enough slabs (<= 256) that the final pass stays short for tall matrices
+// (conv bias gradients reduce over B*H*W rows)
+static int colsum_rps(int M) {
+  int rps = fl::cdiv(M, 256);
+  return rps < 32 ? 32 : rps;
+}
+size_t fl_colsum_workspace_bytes(int M, int N) { return (size_t)fl::cdiv(M, colsum_rps(M)) * N * sizeof(float) + 64; }
 int fl_colsum(const float* x, int64_t ldx, float* out, int M, int N, float alpha, float beta, void* ws, size_t ws_bytes,
               fl_stream_t stream) {
   FL_REQUIRE(ws && ws_bytes >= fl_colsum_workspace_bytes(M, N), "fl_colsum: workspace too small");
   if (!N) return FL_OK;
-  const int rps = 32, slabs = fl::cdiv(M, rps);
+  const int rps = colsum_rps(M), slabs = fl::cdiv(M, rps);
   float* partial = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(fl::cdiv(N, 128), slabs > 0 ? slabs : 1), dim3(128), 0, ST(stream), x, partial, M, N, (long long)ldx, rps);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(fl::cdiv(N, 128)), dim3(128), 0, ST(stream), partial, out, slabs, N, alpha, beta);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(fl::cdiv(N, 64), slabs > 0 ? slabs : 1), dim3(64), 0, ST(stream), x, partial, M, N, (long long)ldx, rps);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(fl::cdiv(N, 64)), dim3(64), 0, ST(stream), partial, out, slabs, N, alpha, beta);
   return fl::check_launch("colsum");
 }
 

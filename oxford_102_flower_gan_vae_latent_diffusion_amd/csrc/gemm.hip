@@ -75,6 +75,7 @@ struct GArgs {
   int splitk, chunks_per_split;
   float* ws;
   int prio_mode;
+  int hw_shift, wo_shift;  // >= 0 when Ho*Wo / Wo are powers of two (pixel decode by shifts), else -1
 };
 
 // 16 zero bytes: source of out-of-bounds / padding lanes of direct-to-LDS loads
@@ -333,8 +334,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
         } else {  // B_KS_IM2COL: reduction index = output pixel, column = (tap, ci)
           const int kks = ok ? kk : 0;
           const int hw = g.Ho * g.Wo;
-          const int img = kks / hw, pp = kks - img * hw;
-          const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
+          int img, pp, oy, ox;
+          if (g.hw_shift >= 0) {  // wave-uniform branch: shifts instead of two integer divisions per load
+            img = kks >> g.hw_shift;
+            pp = kks & (hw - 1);
+            oy = pp >> g.wo_shift;
+            ox = pp & (g.Wo - 1);
+          } else {
+            img = kks / hw;
+            pp = kks - img * hw;
+            oy = pp / g.Wo;
+            ox = pp - oy * g.Wo;
+          }
           const int iy = oy * g.stride - g.pad + b_ky, ix = ox * g.stride - g.pad + b_kx;
           ok = ok & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
           src += (((long long)img * g.H + iy) * g.W + ix) * g.Cin + b_ci;
@@ -618,6 +629,11 @@ int launch_cfg2(GArgs g, int classes, hipStream_t stream) {
   const int tiles_m = fl::cdiv(g.M, BM);
   g.tiles_n = fl::cdiv(g.N, BN);
   {
+    const int hw = g.Ho * g.Wo;
+    g.hw_shift = (hw > 0 && (hw & (hw - 1)) == 0 && g.Wo > 0 && (g.Wo & (g.Wo - 1)) == 0) ? __builtin_ctz(hw) : -1;
+    g.wo_shift = g.hw_shift >= 0 ? __builtin_ctz(g.Wo) : -1;
+  }
+  {
     static int prio = -1;
     if (prio < 0) { const char* e = getenv("FL_GEMM_PRIO"); prio = e ? atoi(e) : 1; }
     g.prio_mode = prio;
@@ -658,10 +674,17 @@ int launch_gemm(GArgs g, int classes, void* ws, size_t ws_bytes, hipStream_t str
   if (g.N <= 32) bn = 32;
   else if (g.N <= 64 || (g.N % 128 != 0 && g.N % 128 <= 64 && g.N < 512)) bn = 64;
   long long tiles = (long long)fl::cdiv(g.M, bm) * fl::cdiv(g.N, bn) * classes;
-  if (bn == 128 && tiles < 192) {  // small problem: smaller tiles fill more CUs
-    bm = 64;
-    bn = 64;
-    tiles = (long long)fl::cdiv(g.M, bm) * fl::cdiv(g.N, bn) * classes;
+  if (bn == 128 && tiles < 192) {
+    // few tiles: with a long reduction keep the MFMA-dense 128x128 tile and fill the chip by split-K (wgrad,
+    // the 32768-wide fc layers); with a short one use 64x64 tiles so that more CUs get a tile at all.
+    const int want = (int)((320 + tiles - 1) / tiles);
+    const bool long_k = g.out_mode == OUT_ROWMAJOR && classes == 1 && ws != nullptr && nk / want >= 16 &&
+                        (size_t)want * g.M * g.N * sizeof(float) <= ws_bytes;
+    if (!long_k) {
+      bm = 64;
+      bn = 64;
+      tiles = (long long)fl::cdiv(g.M, bm) * fl::cdiv(g.N, bn) * classes;
+    }
   }
   // split-K when the grid still cannot fill 256 CUs (row-major epilogue only)
   g.splitk = 1;
