@@ -223,6 +223,35 @@ def unet_forward(sd, x, t, c, block_masks=None, head_masks=None, heads=8):
     return out + torch.sigmoid(sd["residual_weight"]) * F.linear(x, sd["final.weight"], sd["final.bias"])
 
 
+# ----------------------------------------------------------------------------- conv-UNet blocks (defined, never instantiated by v2)
+def unet_attention_block(sd, p, x, num_heads=4):
+    """UNetAttentionBlock v2:434-459: GroupNorm(1,C) -> 1x1 qkv -> per-head softmax(q k^T * d^-1/2) v over h*w tokens
+    -> (quirk, v2:456-457) channels re-ordered d-major -> 1x1 proj + residual."""
+    b, c, h, w = x.shape
+    d = c // num_heads
+    xn = F.group_norm(x, 1, sd[p + "norm.weight"], sd[p + "norm.bias"])
+    qkv = F.conv2d(xn, sd[p + "qkv.weight"], sd[p + "qkv.bias"]).reshape(b, 3, num_heads, d, h * w)
+    q, k, v = qkv[:, 0].permute(0, 1, 3, 2), qkv[:, 1], qkv[:, 2].permute(0, 1, 3, 2)
+    attn = F.softmax(torch.matmul(q, k) * (d ** -0.5), dim=-1)
+    out = torch.matmul(attn, v).permute(0, 3, 1, 2).reshape(b, c, h, w)
+    return F.conv2d(out, sd[p + "proj.weight"], sd[p + "proj.bias"]) + x
+
+
+def unet_residual_block(sd, p, x, t, c=None, mask=None):
+    """UNetResidualBlock v2:462-486 (dropout mask explicit, None = eval)."""
+    h = swish(layernorm2d(sd, p + "norm1.", x))
+    h = F.conv2d(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
+    h = h + swish(F.linear(t, sd[p + "time_emb.weight"], sd[p + "time_emb.bias"]))[:, :, None, None]
+    if c is not None:
+        h = h + swish(F.linear(c, sd[p + "class_emb.weight"], sd[p + "class_emb.bias"]))[:, :, None, None]
+    h = swish(layernorm2d(sd, p + "norm2.", h))
+    if mask is not None:
+        h = h * mask
+    h = F.conv2d(h, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+    res = F.conv2d(x, sd[p + "residual.weight"], sd[p + "residual.bias"]) if (p + "residual.weight") in sd else x
+    return h + res
+
+
 # ----------------------------------------------------------------------------- diffusion process
 def schedule(n_steps=1000, dtype=torch.float32):
     """v2:569-571."""

@@ -202,6 +202,21 @@ __global__ void ce_bwd_kernel(const float* __restrict__ probs, const long long* 
   }
 }
 
+// row softmax of scale*x (attention weights of UNetAttentionBlock, v2:453-454): one block per row
+__global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int D, float scale) {
+  __shared__ float red[8];
+  const long long r = blockIdx.x;
+  const float* xr = x + r * D;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) mx = fmaxf(mx, xr[i] * scale);
+  mx = fl::block_max(mx, red);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) s += expf(xr[i] * scale - mx);
+  s = fl::block_sum(s, red);
+  const float inv = 1.f / s;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) y[r * D + i] = expf(xr[i] * scale - mx) * inv;
+}
+
 // gather rows: out[b,:] = table[idx[b],:]
 __global__ void gather_rows_kernel(const float* __restrict__ table, const long long* __restrict__ idx,
                                    float* __restrict__ out, int B, int D) {
@@ -336,6 +351,11 @@ int fl_cross_entropy_bwd(const float* probs, const int64_t* labels, float gscale
   if (!n) return FL_OK;
   hipLaunchKernelGGL(ce_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), probs, (const long long*)labels, gscale, gdev, dlogits, B, C);
   return fl::check_launch("cross_entropy_bwd");
+}
+int fl_softmax_rows(const float* x, float* y, int rows, int D, float scale, fl_stream_t stream) {
+  if (!rows) return FL_OK;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(D >= 256 ? 256 : 64), 0, ST(stream), x, y, D, scale);
+  return fl::check_launch("softmax_rows");
 }
 int fl_gather_rows(const float* table, const int64_t* idx, float* out, int B, int D, fl_stream_t stream) {
   const long long n = (long long)B * D;

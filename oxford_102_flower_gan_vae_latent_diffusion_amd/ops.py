@@ -568,6 +568,14 @@ def cross_entropy_bwd(probs, labels, gscale=1.0, gdev=None):
     return d
 
 
+def softmax_rows(x, scale=1.0):
+    _chk(x)
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    _lib.call("fl_softmax_rows", _p(x), _p(y), rows, D, float(scale), _stream())
+    return y
+
+
 def gather_rows(table, idx):
     _chk(table, idx)
     out = new((idx.shape[0], table.shape[1]), table)

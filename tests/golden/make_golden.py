@@ -183,6 +183,28 @@ def main():
         **{"reparam_eps%d" % i: d[0] for i, d in enumerate(draws)}, **{"t%d" % i: d[1] for i, d in enumerate(draws)},
         **{"eps%d" % i: d[2] for i, d in enumerate(draws)}, **slices(sd_after, UNET_KEYS))
 
+    # ------------------------------------------------------------------ conv-UNet blocks (dead code in v2, A18)
+    attn = mod.UNetAttentionBlock(64, num_heads=4)
+    attn.load_state_dict(pinit.procedural_state_dict(attn.state_dict(), 45))
+    rbk = mod.UNetResidualBlock(64, 128, d_time=256, dropout_rate=0.2)
+    rbk.load_state_dict(pinit.procedural_state_dict(rbk.state_dict(), 46))
+    rbk2 = mod.UNetResidualBlock(128, 128, d_time=256)
+    rbk2.load_state_dict(pinit.procedural_state_dict(rbk2.state_dict(), 47))
+    attn2 = mod.UNetAttentionBlock(128, num_heads=4)
+    attn2.load_state_dict(pinit.procedural_state_dict(attn2.state_dict(), 48))
+    seq = mod.SwitchSequential(rbk, attn2, rbk2).eval()
+    attn.eval()
+    xa = torch.randn(2, 64, 8, 8, generator=g(70))
+    tt, cc2 = torch.randn(2, 256, generator=g(71)), torch.randn(2, 256, generator=g(72))
+    shapes["dead_blocks"] = {"attn64": {k: list(v.shape) for k, v in attn.state_dict().items()},
+                             "res64_128": {k: list(v.shape) for k, v in rbk.state_dict().items()},
+                             "res128": {k: list(v.shape) for k, v in rbk2.state_dict().items()},
+                             "attn128": {k: list(v.shape) for k, v in attn2.state_dict().items()}}
+    json.dump(shapes, open(os.path.join(HERE, "state_dict_shapes.json"), "w"), indent=0)
+    with torch.no_grad():
+        npz("dead_blocks", x=xa, t=tt, c=cc2, attn=attn(xa), res=rbk(xa, tt, cc2), res_noc=rbk(xa, tt, None),
+            seq=seq(xa, tt, cc2))
+
     # ------------------------------------------------------------------ discriminator (v2:983-1007)
     xd = torch.rand(4, 3, 64, 64, generator=g(50))
     disc.train()

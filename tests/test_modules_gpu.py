@@ -247,3 +247,23 @@ def test_pipelined_trainer_equals_plain_trainer(dev):
         losses_b.append(float(l))
     close(torch.tensor(losses_b), torch.tensor(losses_a), 1e-6, "loss sequence")
     assert torch.equal(tr.fp.flat, pa), "pipelined parameters differ from the plain step"
+
+
+def test_dead_conv_unet_blocks_vs_reference(dev):
+    """A18: the conv-UNet blocks v2 defines but never uses (true QK^T / softmax / PV attention)."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import unet_blocks as U
+    f = load("dead_blocks")
+    attn = seeded(U.UNetAttentionBlock(64, num_heads=4), 45).to(dev).eval()
+    rb1 = seeded(U.UNetResidualBlock(64, 128, d_time=256, dropout_rate=0.2), 46).to(dev).eval()
+    rb2 = seeded(U.UNetResidualBlock(128, 128, d_time=256), 47).to(dev).eval()
+    attn2 = seeded(U.UNetAttentionBlock(128, num_heads=4), 48).to(dev).eval()
+    ref_shapes = json.load(open(os.path.join(G, "state_dict_shapes.json")))["dead_blocks"]
+    for m, k in ((attn, "attn64"), (rb1, "res64_128"), (rb2, "res128"), (attn2, "attn128")):
+        assert {n: list(v.shape) for n, v in m.state_dict().items()} == ref_shapes[k]
+    x, t, c = f["x"].to(dev), f["t"].to(dev), f["c"].to(dev)
+    with torch.no_grad():
+        close(attn(x), f["attn"], 5e-5, "UNetAttentionBlock")
+        close(rb1(x, t, c), f["res"], 5e-5, "UNetResidualBlock")
+        close(rb1(x, t, None), f["res_noc"], 5e-5, "UNetResidualBlock (no class)")
+        seq = U.SwitchSequential(rb1, attn2, rb2)
+        close(seq(x, t, c), f["seq"], 1e-4, "SwitchSequential")

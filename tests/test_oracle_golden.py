@@ -166,3 +166,20 @@ def test_vae_gan_loop_matches_reference_loop(ae_sd, d_sd):
     for k in [k for k in f if k.startswith("d__")]:
         key = k[3:].replace("__", ".")
         close(dd[key].reshape(-1)[:64], f[k], 3e-4, "post-step D " + key)
+
+
+def test_dead_conv_unet_blocks():
+    """UNetAttentionBlock / UNetResidualBlock / SwitchSequential (v2:434-498) instantiated directly in the reference."""
+    f = load("dead_blocks")
+    sh = json.load(open(os.path.join(G, "state_dict_shapes.json")))["dead_blocks"]
+    a64 = pinit.procedural_state_dict(sh["attn64"], 45)
+    r1 = pinit.procedural_state_dict(sh["res64_128"], 46)
+    r2 = pinit.procedural_state_dict(sh["res128"], 47)
+    a128 = pinit.procedural_state_dict(sh["attn128"], 48)
+    close(O.unet_attention_block(a64, "", f["x"]), f["attn"], 3e-5, "attention block")
+    close(O.unet_residual_block(r1, "", f["x"], f["t"], f["c"]), f["res"], 3e-5, "residual block")
+    close(O.unet_residual_block(r1, "", f["x"], f["t"], None), f["res_noc"], 3e-5, "residual block (no class)")
+    h = O.unet_residual_block(r1, "", f["x"], f["t"], f["c"])
+    h = O.unet_attention_block(a128, "", h)
+    h = O.unet_residual_block(r2, "", h, f["t"], f["c"])
+    close(h, f["seq"], 5e-5, "SwitchSequential")
