@@ -55,3 +55,20 @@ class GraphSampler:
         if was_training:
             d.eps_model.train()
         return self.x
+
+
+# ---- visualisation-facing helpers: the access patterns of visualize_denoising_steps (v2:687-691) and
+# create_diffusion_animation (v2:928-935) as batched device-side operations ------------------------------------------
+@torch.no_grad()
+def denoise_from(diffusion, x_t, t_start, c=None, use_graph=True):
+    """Run the reverse process from step `t_start` down to 0 starting at x_t (v2:687-691 restarts from the same x_T for
+    several t values; pass x_T and t_start = n_steps-1 for a full trajectory)."""
+    g = GraphSampler(diffusion, tuple(x_t.shape), x_t.device, c, use_graph=use_graph)
+    return g.run(x_T=x_t, n_steps=int(t_start) + 1, t_start=int(t_start))
+
+
+@torch.no_grad()
+def renoise(diffusion, x0, t, eps=None):
+    """x_t ~ q(x_t | x_0) for an integer t shared by the batch (v2:928-935 uses alpha_bar[t] directly)."""
+    tt = torch.full((x0.shape[0],), int(t), dtype=torch.int64, device=x0.device)
+    return diffusion.q_sample(x0, tt, eps)
