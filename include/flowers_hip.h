@@ -77,6 +77,13 @@ int fl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y,
                   int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
                   int act, float act_param, const float* R, int out_nchw,
                   void* ws, size_t ws_bytes, fl_stream_t stream);
+/* Same convolution with the LayerNorm2d statistics of its output (v2:152-153) accumulated in the GEMM epilogue:
+ * emits y plus per-(image,channel) scale/shift/mean/rstd (norm(y) = y*scale + shift) — no separate statistics pass. */
+size_t fl_conv2d_fwd_instnorm_workspace_bytes(int B, int Ho, int Wo, int Cout);
+int fl_conv2d_fwd_instnorm(const float* x, const float* wp, const float* bias, float* y, int B, int H, int W, int Cin,
+                           int Cout, int kh, int kw, int stride, int pad, const float* ln_w, const float* ln_b,
+                           float eps, float* scale, float* shift, float* mean, float* rstd, void* ws, size_t ws_bytes,
+                           fl_stream_t stream);
 /* dx = conv_transpose(dy, w): input gradient of the conv above (stride 1 any
  * kernel; stride 2 only for 4x4 p1).  dy:(B,Ho,Wo,Cout) -> dx:(B,H,W,Cin).
  * wp is the SAME packed weight as the forward. */

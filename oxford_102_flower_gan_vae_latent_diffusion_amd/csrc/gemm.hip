@@ -75,6 +75,7 @@ struct GArgs {
   int splitk, chunks_per_split;
   float* ws;
   int prio_mode;
+  float* stats;  // optional [M/WM][2][N] per-wave column sums (sum y, sum y^2) of the epilogue output (fused LayerNorm2d stats)
   int hw_shift, wo_shift;  // >= 0 when Ho*Wo / Wo are powers of two (pixel decode by shifts), else -1
 };
 
@@ -560,6 +561,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
 
   // ------------------------------------------------------------------ epilogue
   // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float st1[TN], st2[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) st1[tn] = st2[tn] = 0.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -597,7 +601,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
         const int col = tile_n0 + wc * WN + tn * 32 + li;
         if (col >= g.N) continue;
         const float* rptr = g.R ? g.R + rrow_off + (long long)col * col_stride : nullptr;
-        g.C[row_off + (long long)col * col_stride] = epilogue_value(g, acc[tm][tn][e], col, rptr);
+        const float v = epilogue_value(g, acc[tm][tn][e], col, rptr);
+        g.C[row_off + (long long)col * col_stride] = v;
+        st1[tn] += v;
+        st2[tn] += v * v;
+      }
+    }
+  }
+  // fused LayerNorm2d statistics (v2:152-153): this wave's WM rows belong to one image (host guarantees HW % WM == 0),
+  // so its column sums are one slab of that image's (sum y, sum y^2); the two lane halves hold disjoint rows.
+  if (g.stats && g.splitk <= 1) {
+    const int grp = (tile_m0 + wr * WM) / WM;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const float a = st1[tn] + __shfl_xor(st1[tn], 32, 64);
+      const float b = st2[tn] + __shfl_xor(st2[tn], 32, 64);
+      const int col = tile_n0 + wc * WN + tn * 32 + li;
+      if (lh == 0 && col < g.N && tile_m0 + wr * WM < g.M) {
+        g.stats[((long long)grp * 2) * g.N + col] = a;
+        g.stats[((long long)grp * 2 + 1) * g.N + col] = b;
       }
     }
   }
@@ -666,7 +688,7 @@ int launch_cfg(GArgs g, int classes, hipStream_t stream) {
 
 // tile-shape + split-K policy. `classes` = 4 for transposed conv, else 1.
 template <int AM, int BMODE>
-int launch_gemm(GArgs g, int classes, void* ws, size_t ws_bytes, hipStream_t stream) {
+int launch_gemm(GArgs g, int classes, void* ws, size_t ws_bytes, hipStream_t stream, int* wm_out = nullptr) {
   if (g.M <= 0 || g.N <= 0) return FL_OK;
   const int nk = fl::cdiv(g.K, BK);
   // pick tile
@@ -701,6 +723,9 @@ int launch_gemm(GArgs g, int classes, void* ws, size_t ws_bytes, hipStream_t str
       g.splitk = fl::cdiv(nk, g.chunks_per_split);
     }
   }
+  if (wm_out) *wm_out = (bm == 128 && bn == 32) ? 32 : bm / 2;  // rows per wave tile (WM) of the chosen config
+  if (g.stats) g.splitk = 1;                                     // fused statistics need the final values in the epilogue
+  if (g.splitk <= 1) g.chunks_per_split = nk;
   int st;
   if (bm == 128 && bn == 128) st = launch_cfg<128, 128, 2, 2, AM, BMODE>(g, classes, stream);
   else if (bm == 128 && bn == 64) st = launch_cfg<128, 64, 2, 2, AM, BMODE>(g, classes, stream);
@@ -754,10 +779,68 @@ __global__ void unpack_w_kernel(const float* __restrict__ wp, float* __restrict_
   }
 }
 
+// per-(image, channel) LayerNorm2d scale/shift from the conv epilogue's per-wave slabs (same math as norm.hip)
+__global__ void conv_inorm_finalize(const float* partial, const float* w, const float* bias, float eps, float* scale,
+                                    float* shift, float* mean, float* rstd, int B, int HW, int C, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < S; ++s) {
+    const float* p = partial + ((long long)(b * S + s) * 2) * C + c;
+    s1 += (double)p[0];
+    s2 += (double)p[C];
+  }
+  const double m = s1 / HW;
+  double var = s2 / HW - m * m;
+  if (var < 0.0) var = 0.0;
+  const float r = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = r * (w ? w[c] : 1.f);
+  scale[i] = sc;
+  shift[i] = (bias ? bias[c] : 0.f) - (float)m * sc;
+  if (mean) mean[i] = (float)m;
+  if (rstd) rstd[i] = r;
+}
+
 }  // namespace
 
 // =====================================================================================
 extern "C" {
+
+size_t fl_conv2d_fwd_instnorm_workspace_bytes(int B, int Ho, int Wo, int Cout) {
+  return ((size_t)B * Ho * Wo / 32 + 1) * 2 * (size_t)Cout * sizeof(float);
+}
+
+// conv (+bias) with the LayerNorm2d statistics of its OUTPUT accumulated in the epilogue, then finalized to
+// per-(image,channel) scale/shift/mean/rstd: replaces conv -> LayerNorm2d statistics pass (v2:162-163, 186-187, 192-193).
+int fl_conv2d_fwd_instnorm(const float* x, const float* wp, const float* bias, float* y, int B, int H, int W, int Cin,
+                           int Cout, int kh, int kw, int stride, int pad, const float* ln_w, const float* ln_b,
+                           float eps, float* scale, float* shift, float* mean, float* rstd, void* ws, size_t ws_bytes,
+                           fl_stream_t stream) {
+  FL_REQUIRE(x && wp && y && scale && shift, "fl_conv2d_fwd_instnorm: null operand");
+  FL_REQUIRE(Cin % 4 == 0, "fl_conv2d_fwd_instnorm: Cin must be a multiple of 4");
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  const int HW = Ho * Wo;
+  FL_REQUIRE(HW % 64 == 0, "fl_conv2d_fwd_instnorm: H*W of the output must be a multiple of 64");
+  FL_REQUIRE(ws && ws_bytes >= fl_conv2d_fwd_instnorm_workspace_bytes(B, Ho, Wo, Cout), "fl_conv2d_fwd_instnorm: workspace too small");
+  GArgs g = base_args();
+  g.M = B * HW; g.N = Cout; g.K = kh * kw * Cin;
+  g.A = x; g.a_vec = is_vec(x, Cin);
+  g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.kw = kw; g.stride = stride; g.pad = pad;
+  g.B = wp; g.ldb = g.K; g.b_vec = is_vec(wp, g.K);
+  g.C = y; g.ldc = Cout; g.out_mode = OUT_ROWMAJOR;
+  g.bias = bias; g.ldr = Cout;
+  g.stats = reinterpret_cast<float*>(ws);
+  int wm = 64;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = launch_gemm<A_KC_CONV, B_KC_PLAIN>(g, 1, nullptr, 0, s, &wm);
+  if (rc) return rc;
+  const int S = HW / wm;
+  hipLaunchKernelGGL(conv_inorm_finalize, dim3(fl::cdiv((long long)B * Cout, 256)), dim3(256), 0, s, g.stats, ln_w, ln_b, eps,
+                     scale, shift, mean, rstd, B, HW, Cout, S);
+  return fl::check_launch("conv_inorm_finalize");
+}
+
 
 size_t fl_gemm_workspace_bytes(int M, int N, int K) {
   const int nk = fl::cdiv(K, BK);

@@ -49,11 +49,11 @@ def ca_gate(ca, pooled):
 
 def resblock_infer(x, rb, pk):
     """ResidualBlock.forward (v2:170-178), NHWC, no saved state. 2 convs + 2 stats passes + 3 streaming passes."""
-    y1 = ops.conv2d_fwd(x, pk.conv(rb.conv1), _d(rb.conv1.bias), 1, 1)
-    sc, sh, _, _ = ops.instnorm_stats(y1, _d(rb.ln1.weight), _d(rb.ln1.bias), rb.ln1.eps)
+    y1, (sc, sh, _, _) = ops.conv2d_fwd_instnorm(x, pk.conv(rb.conv1), _d(rb.conv1.bias), 1, 1, _d(rb.ln1.weight),
+                                                 _d(rb.ln1.bias), rb.ln1.eps)
     a1 = ops.affine_act(y1, sc, sh, act=SW, out=y1)
-    y2 = ops.conv2d_fwd(a1, pk.conv(rb.conv2), _d(rb.conv2.bias), 1, 1)
-    sc2, sh2, _, _ = ops.instnorm_stats(y2, _d(rb.ln2.weight), _d(rb.ln2.bias), rb.ln2.eps)
+    y2, (sc2, sh2, _, _) = ops.conv2d_fwd_instnorm(a1, pk.conv(rb.conv2), _d(rb.conv2.bias), 1, 1, _d(rb.ln2.weight),
+                                                   _d(rb.ln2.bias), rb.ln2.eps)
     # avg_pool(LayerNorm2d(y)) == ln2.bias exactly (normalised maps have zero spatial mean), so the
     # channel-attention gate (v2:65-66) is one (C,) vector shared by the batch: no pooling pass.
     s = ca_gate(rb.ca, _d(rb.ln2.bias).view(1, -1)).view(-1)
@@ -74,14 +74,13 @@ def encoder_infer(enc, x):
     B = x.shape[0]
     h = ops.nchw_to_nhwc(x, 4)
     c0, ln0 = enc.initial_conv[0], enc.initial_conv[1]
-    y = ops.conv2d_fwd(h, pk.conv(c0), _d(c0.bias), 1, 1)
-    sc, sh, _, _ = ops.instnorm_stats(y, _d(ln0.weight), _d(ln0.bias), ln0.eps)
+    y, (sc, sh, _, _) = ops.conv2d_fwd_instnorm(h, pk.conv(c0), _d(c0.bias), 1, 1, _d(ln0.weight), _d(ln0.bias), ln0.eps)
     h = ops.affine_act(y, sc, sh, act=SW, out=y)
     feats = [h]
     for i in (1, 2, 3):
         dn, rb = getattr(enc, "down%d" % i), getattr(enc, "res%d" % i)
-        y = ops.conv2d_fwd(h, pk.conv(dn[0]), _d(dn[0].bias), 2, 1)
-        sc, sh, _, _ = ops.instnorm_stats(y, _d(dn[1].weight), _d(dn[1].bias), dn[1].eps)
+        y, (sc, sh, _, _) = ops.conv2d_fwd_instnorm(h, pk.conv(dn[0]), _d(dn[0].bias), 2, 1, _d(dn[1].weight),
+                                                    _d(dn[1].bias), dn[1].eps)
         h = ops.affine_act(y, sc, sh, act=SW, out=y)
         h = resblock_infer(h, rb, pk)
         feats.append(h)

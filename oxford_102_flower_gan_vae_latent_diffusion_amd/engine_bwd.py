@@ -63,11 +63,11 @@ def _ca_mlp_bwd(saved, ds):
 def resblock_fwd(x, rb, pk):
     S = RBSaved()
     S.x = x
-    S.y1 = ops.conv2d_fwd(x, pk.conv(rb.conv1), _d(rb.conv1.bias), 1, 1)
-    S.n1 = ops.instnorm_stats(S.y1, _d(rb.ln1.weight), _d(rb.ln1.bias), rb.ln1.eps)
+    S.y1, S.n1 = ops.conv2d_fwd_instnorm(x, pk.conv(rb.conv1), _d(rb.conv1.bias), 1, 1, _d(rb.ln1.weight),
+                                         _d(rb.ln1.bias), rb.ln1.eps)
     S.a1 = ops.affine_act(S.y1, S.n1[0], S.n1[1], act=SW)
-    S.y2 = ops.conv2d_fwd(S.a1, pk.conv(rb.conv2), _d(rb.conv2.bias), 1, 1)
-    S.n2 = ops.instnorm_stats(S.y2, _d(rb.ln2.weight), _d(rb.ln2.bias), rb.ln2.eps)
+    S.y2, S.n2 = ops.conv2d_fwd_instnorm(S.a1, pk.conv(rb.conv2), _d(rb.conv2.bias), 1, 1, _d(rb.ln2.weight),
+                                         _d(rb.ln2.bias), rb.ln2.eps)
     s, S.ca = _ca_mlp_fwd(rb.ca, _d(rb.ln2.bias).view(1, -1))  # avg_pool(LN2d(.)) == ln2.bias (see engine.resblock_infer)
     S.s = s.view(-1)
     S.saw = _d(rb.sa.conv.weight).contiguous()
@@ -134,16 +134,15 @@ def encoder_fwd(enc, x):
     B = x.shape[0]
     S.x4 = ops.nchw_to_nhwc(x, 4)
     c0, ln0 = enc.initial_conv[0], enc.initial_conv[1]
-    S.y0 = ops.conv2d_fwd(S.x4, pk.conv(c0), _d(c0.bias), 1, 1)
-    S.n0 = ops.instnorm_stats(S.y0, _d(ln0.weight), _d(ln0.bias), ln0.eps)
+    S.y0, S.n0 = ops.conv2d_fwd_instnorm(S.x4, pk.conv(c0), _d(c0.bias), 1, 1, _d(ln0.weight), _d(ln0.bias), ln0.eps)
     h = ops.affine_act(S.y0, S.n0[0], S.n0[1], act=SW)
     S.stages = []
     feats = [h]
     for i in (1, 2, 3):
         dn, rb = getattr(enc, "down%d" % i), getattr(enc, "res%d" % i)
         hin = h
-        yd = ops.conv2d_fwd(hin, pk.conv(dn[0]), _d(dn[0].bias), 2, 1)
-        nd = ops.instnorm_stats(yd, _d(dn[1].weight), _d(dn[1].bias), dn[1].eps)
+        yd, nd = ops.conv2d_fwd_instnorm(hin, pk.conv(dn[0]), _d(dn[0].bias), 2, 1, _d(dn[1].weight), _d(dn[1].bias),
+                                         dn[1].eps)
         ad = ops.affine_act(yd, nd[0], nd[1], act=SW)
         h, Srb = resblock_fwd(ad, rb, pk)
         S.stages.append((hin, yd, nd, Srb))

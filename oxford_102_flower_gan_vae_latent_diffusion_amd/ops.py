@@ -173,6 +173,24 @@ def conv2d_fwd(x, wp, bias, stride, pad, act=ACT_NONE, act_param=0.0, R=None, ou
     return out
 
 
+def conv2d_fwd_instnorm(x, wp, bias, stride, pad, ln_w, ln_b, eps=1e-5):
+    """conv (+bias) whose epilogue also accumulates the LayerNorm2d statistics of the output.
+    -> y (B,Ho,Wo,Cout), (scale, shift, mean, rstd) each (B,Cout)."""
+    _chk(x, wp, bias, ln_w, ln_b)
+    B, H, W, Cin = x.shape
+    Cout, kh, kw, _ = wp.shape
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if (Ho * Wo) % 64 != 0:  # tiny maps: separate statistics pass
+        y = conv2d_fwd(x, wp, bias, stride, pad)
+        return y, instnorm_stats(y, ln_w, ln_b, eps)
+    y = new((B, Ho, Wo, Cout), x)
+    scale, shift, mean, rstd = (new((B, Cout), x) for _ in range(4))
+    wsp, wsn = _ws(_lib.load().fl_conv2d_fwd_instnorm_workspace_bytes(B, Ho, Wo, Cout), x)
+    _lib.call("fl_conv2d_fwd_instnorm", _p(x), _p(wp), _p(bias), _p(y), B, H, W, Cin, Cout, kh, kw, stride, pad, _p(ln_w),
+              _p(ln_b), float(eps), _p(scale), _p(shift), _p(mean), _p(rstd), wsp, wsn, _stream())
+    return y, (scale, shift, mean, rstd)
+
+
 def conv2d_dgrad(dy, wp, in_hw, stride, pad, out=None):
     _chk(dy, wp, out)
     B, Ho, Wo, Cout = dy.shape
