@@ -45,6 +45,8 @@ def _chk(*ts):
             raise RuntimeError("flowers_hip ops need device tensors (got %s); there is no CPU path" % t.device)
         if not t.is_contiguous():
             raise RuntimeError("flowers_hip ops need contiguous tensors")
+        if t.is_floating_point() and t.dtype != torch.float32:
+            raise TypeError("flowers_hip kernels are fp32 (got %s)" % t.dtype)
 
 
 def workspace(nbytes, device=None):

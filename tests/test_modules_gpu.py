@@ -322,3 +322,34 @@ def test_sampler_helpers(dev, unet):
     xt = sampler.renoise(d, a, 500, eps)
     ab = d.alpha_bar[500]
     close(xt, torch.sqrt(ab) * a + torch.sqrt(1 - ab) * eps, 1e-6, "renoise")
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_edge_batch_sizes_vs_oracle(dev, ae, unet, B):
+    """ragged / minimal batches: tile masks, split-K and the fused-statistics epilogue must not depend on B."""
+    g = torch.Generator().manual_seed(100 + B)
+    data, eps = torch.rand(B, 3, 64, 64, generator=g), torch.randn(B, 256, generator=g)
+    ae_sd = {k: v.detach().cpu() for k, v in ae.state_dict().items()}
+    un_sd = {k: v.detach().cpu() for k, v in unet.state_dict().items()}
+    with torch.no_grad():
+        recon, mu, logvar, z = ae(data.to(dev), eps=eps.to(dev))
+        r_ref, mu_ref, lv_ref, z_ref = O.autoencoder_forward(ae_sd, data, eps)
+        close(mu, mu_ref, 1e-4, "mu B=%d" % B)
+        close(logvar, lv_ref, 1e-4, "logvar")
+        close(recon, r_ref, 2e-4, "recon")
+        t = torch.randint(0, 1000, (B,), generator=g)
+        c = torch.randint(0, 102, (B,), generator=g)
+        x = torch.randn(B, 256, generator=g)
+        close(unet(x.to(dev), t.to(dev), c.to(dev)), O.unet_forward(un_sd, x, t, c), 1e-4, "unet B=%d" % B)
+        close(unet(x.to(dev), torch.tensor([7], device=dev), c.to(dev)), O.unet_forward(un_sd, x, torch.tensor([7]), c), 1e-4,
+              "unet shared t")
+
+
+def test_unsupported_inputs_fail_loudly(dev, ae):
+    with pytest.raises(RuntimeError):
+        ae.encoder(torch.zeros(2, 3, 32, 32, device=dev))          # SURVEY M5: the reference also rejects 32x32
+    with pytest.raises(TypeError):
+        ae.decode(torch.zeros(2, 256, device=dev, dtype=torch.float64))
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.conv2d_fwd(torch.zeros(1, 8, 8, 3, device=dev), torch.zeros(8, 3, 3, 3, device=dev), None, 1, 1)  # Cin % 4
