@@ -252,6 +252,64 @@ int fl_mul(const float* a, const float* b, float* out, int64_t n, fl_stream_t st
 int fl_clamp_bwd(const float* d, const float* x, float lo, float hi, float* out, int64_t n, fl_stream_t stream); /* v2:352 */
 int fl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, int64_t n, fl_stream_t stream); /* v2:339-343 */
 
+/* ------------------------------------------------------------------------ *
+ * Persistent phase-program executor ("persistent fused fwd"): the
+ * ConditionalUNet forward (v2:534-561) is ~35 dependent M=B GEMMs + row
+ * LayerNorms, each far too small to amortise a kernel launch (>= 4.5 us per
+ * graph node on MI355X). A *program* is a list of phases; a phase is a list of
+ * independent jobs; one persistent grid (one 256-thread block per CU) executes
+ * the phases in order with a device-wide barrier in between.
+ *
+ * Job kinds
+ *   FL_PJOB_GEMM     C[M,N] = epi( sum_s A_s[M,K_s] * W_s[N,K_s]^T )  (nn.Linear layout; up to 3 concatenated-K
+ *                    segments, e.g. h + time_proj(tc) of v2:543-544 as ONE contraction); epilogue:
+ *                    v = acc + sum_s bias_scale_s*bias_s (all * (1+sigmoid(*gate)) when gate != 0); v = act(v);
+ *                    v *= colmask[row, col/mask_group]; v += R[row, col].   N % 32 == 0, K_s % 32 == 0; lda may be 0
+ *                    (one shared row, the (1,) timestep of v2:583).
+ *   FL_PJOB_ROWNORM  y1 = act(mask * LN(x; W[0], bias[0], eps)) + R + sigmoid(*gate) * aux[1];  C = y1;
+ *                    if W[1]: aux[0] = LN(y1; W[1], bias[1], eps2).   N = row width, N % 256 == 0, N <= 1024.
+ *   FL_PJOB_SINUSOID C[M,N] = [sin(t*f) | cos(t*f)], t = (int64*)A[0] with element stride lda[0], f = W[0] (N/2 freqs).
+ *   FL_PJOB_GATHER   C[M,N] = table A[0] rows picked by (int64*)W[0].
+ * Pointer fields hold a device address, 0 (none), or a small integer 1..FL_PROG_MAX_IO naming slot (value-1) of the
+ * `io` array handed to fl_program_run (inputs/outputs that change per call while the program stays resident).
+ * ------------------------------------------------------------------------ */
+#define FL_PROG_MAX_IO 16
+#define FL_PROG_MAX_SEG 3
+enum { FL_PJOB_GEMM = 0, FL_PJOB_ROWNORM = 1, FL_PJOB_SINUSOID = 2, FL_PJOB_GATHER = 3 };
+typedef struct fl_pjob {
+  uint64_t A[FL_PROG_MAX_SEG], W[FL_PROG_MAX_SEG], bias[FL_PROG_MAX_SEG];
+  uint64_t R, C, mask, gate;
+  uint64_t aux[4];
+  int32_t kind, M, N, nseg;
+  int32_t K[FL_PROG_MAX_SEG], lda[FL_PROG_MAX_SEG], ldw[FL_PROG_MAX_SEG];
+  int32_t ldr, ldc, act, mask_group;
+  int32_t tile_begin, ntiles; /* tiles of this job inside its phase: [tile_begin, tile_begin + ntiles) */
+  float bias_scale[FL_PROG_MAX_SEG];
+  float eps, eps2;
+  int32_t pad_[2];
+} fl_pjob; /* 240 bytes, no implicit padding */
+#define FL_PPHASE_ACQUIRE 1 /* flags: invalidate L1/L2 before this phase (it re-reads a buffer that an earlier phase of
+                              the same run overwrote AFTER some block had read it; a run starts with clean caches) */
+typedef struct fl_pphase {
+  int32_t job_begin, job_end, ntiles, flags;
+} fl_pphase;
+/* sizeof(fl_pjob) / sizeof(fl_pphase) as compiled: the host-side builder asserts its packing against these */
+int fl_program_job_bytes(void);
+int fl_program_phase_bytes(void);
+/* tiles a job occupies (GEMM: ceil(M/32)*(N/32); ROWNORM: ceil(M/4); SINUSOID: ceil(M*N/2/256); GATHER: ceil(M*N/1024));
+ * negative fl_status if the job violates the shape rules above. `job` is a HOST pointer. */
+int fl_program_job_tiles(const void* job);
+/* Bytes of the barrier area `sync` (arrival counters spread over memory channels, departures, abort flag). */
+int fl_program_sync_bytes(void);
+#define FL_PROG_SYNC_ABORT_WORD (8 * 1024 + 16) /* uint32 index inside `sync`: != 0 after a run = a barrier timed out */
+/* Run a device-resident program (n_phases*16 + n_jobs*240 bytes <= 24 KiB: it is copied to LDS). `io`: HOST array of
+ * n_io device pointers (read at call time). `sync`: fl_program_sync_bytes() zeroed device bytes owned by the caller,
+ * reused across runs (abort word != 0 afterwards: the run is void and the caller must zero `sync`). max_blocks: 0 =
+ * one block per CU. Concurrent runs must not share `sync`; two programs running at once on one device may each wait
+ * for CUs the other holds until the barrier timeout fires. */
+int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_jobs, const void* const* io, int n_io,
+                   void* sync, int max_blocks, fl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,644 @@
+// Persistent phase-program executor (include/flowers_hip.h, "Persistent phase-program executor").
+//
+// Why: the live denoiser of v2 (ConditionalUNet, v2:501-561) is a chain of ~35 dependent GEMMs with M = batch (256)
+// and N, K in {256, 512, 1024}, plus row LayerNorms. One such GEMM is 3.4 us of MFMA work at most, while a kernel
+// node of a hipGraph costs >= 4.5 us on MI355X whatever it does: the multi-kernel forward is launch-bound (71 nodes,
+// 422 us, profiles/r01_unet_fwd_timeline.txt). Here ONE grid of (#CU) blocks stays resident and walks the phases;
+// dependent phases are separated by a device-wide barrier.
+//
+// GEMM tile = 32x32 outputs per block. K is walked in 256-wide chunks: all 256 threads fetch the A and W chunk rows
+// with fully coalesced dwordx4 loads (a wave covers one 1 KB row slice), park them in LDS ([row][256+4] images,
+// conflict-free for ds_read_b128), and each of the four waves contracts its own 64-wide k slice with
+// v_mfma_f32_32x32x2_f32 (exact fp32); the four partial tiles meet in LDS and all threads run the epilogue. (A first
+// version loaded MFMA fragments straight from global memory: every lane then touches its own cache line and the
+// texture addresser needs ~57 cycles per load instruction - 5 us just to ISSUE one tile's loads.)
+// Two register stages + two LDS stages keep two chunks (2 x 2048 MFMA cycles) of loads in flight.
+//
+// Barrier: arrivals are spread over 8 counters 4 KB apart (memory-side atomics on one address serialise at ~25 ns
+// each: 6.4 us for 256 blocks), pollers sum the 8 with relaxed sc1 loads; outputs are stored write-through so no L2
+// write-back is needed; the invalidating acquire only where the program says a buffer is re-read after being re-written.
+// The program itself is copied to LDS once (a cold descriptor fetch costs 1-2.5 us per phase otherwise).
+#include <cstddef>
+#include <mutex>
+
+#include "fl_common.h"
+
+namespace {
+
+constexpr int TS = 32;             // output tile edge
+constexpr int KC = 256;            // k values per block chunk (64 per wave)
+constexpr int LDK = KC + 4;        // LDS row stride of a chunk image (floats)
+constexpr int STAGE = 2 * TS * LDK;  // floats per LDS stage: 32 A rows then 32 W rows
+constexpr int SLD = 36;            // LDS row stride of a partial output tile (floats)
+constexpr int PROG_LDS_BYTES = 24 * 1024;  // LDS copy of the program (phases + jobs)
+constexpr int LDS_BYTES = 2 * STAGE * 4 + PROG_LDS_BYTES;
+constexpr int NCTR = 8;            // arrival counters
+constexpr int CTR_STRIDE = 1024;   // ... this many uints apart (4 KB)
+constexpr int SYNC_UINTS = (NCTR + 1) * CTR_STRIDE;
+constexpr unsigned SPIN_LIMIT = 1u << 21;  // barrier polls before a run is declared dead (~ seconds)
+
+// -DFL_PROG_TRACE: timing-only build; io slot 15 is a uint64 buffer [block][phase][12] of 100 MHz wall-clock stamps
+#ifndef FL_PROG_TRACE
+#define FL_PROG_TRACE 0
+#endif
+#if FL_PROG_TRACE
+__shared__ unsigned long long* g_trace;  // only thread 0 of the block touches these
+__shared__ int g_trace_phases, g_trace_p;
+#define FL_STAMP(k)                                                                                        \
+  do {                                                                                                     \
+    if (threadIdx.x == 0 && g_trace) g_trace[((size_t)blockIdx.x * g_trace_phases + g_trace_p) * 12 + (k)] = wall_clock64(); \
+  } while (0)
+#else
+#define FL_STAMP(k) do {} while (0)
+#endif
+
+struct ProgIO {
+  const void* p[FL_PROG_MAX_IO];
+};
+
+// io slots are bound when the program is copied to LDS (program_kernel): descriptors hold plain addresses here
+__device__ __forceinline__ const float* rp(uint64_t v, const ProgIO&) { return reinterpret_cast<const float*>(v); }
+__device__ __forceinline__ float* wp(uint64_t v, const ProgIO& io) { return const_cast<float*>(rp(v, io)); }
+
+// every operand lives in global memory: say so (pointers rebuilt from integers would otherwise be FLAT accesses,
+// which tick both counters and make every wait a full drain)
+typedef __attribute__((address_space(1))) const f32x4v gf4_t;  // native vector type: no struct copy through a generic ref
+typedef __attribute__((address_space(1))) f32x4v gf4w_t;
+typedef __attribute__((address_space(3))) f32x4v lf4_t;
+typedef __attribute__((address_space(3))) float lf1_t;
+__device__ __forceinline__ float4 ld4g(const float* p) {
+  const f32x4v t = *(gf4_t*)(p);
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+// Outputs are stored write-through (sc0 sc1: at memory, visible device-wide, once acknowledged - vmcnt), so the barrier
+// needs no L2 write-back (buffer_wbl2 costs 1.2-2.3 us per block and phase). -DFL_PROG_WT_STORES=0 restores plain stores
+// + a release fence per block.
+#ifndef FL_PROG_WT_STORES
+#define FL_PROG_WT_STORES 1
+#endif
+__device__ __forceinline__ f32x4v ld4gv(const float* p) { return *(gf4_t*)(p); }
+__device__ __forceinline__ float ld1g(const float* p) { return *(__attribute__((address_space(1))) const float*)(p); }
+__device__ __forceinline__ void st1g(float* p, float v) {
+#if FL_PROG_WT_STORES
+  asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  *(__attribute__((address_space(1))) float*)(p) = v;
+#endif
+}
+__device__ __forceinline__ long long ldi64g(const long long* p) { return *(__attribute__((address_space(1))) const long long*)(p); }
+__device__ __forceinline__ void st4g(float* p, const float4& v) {
+  f32x4v t;
+  t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+#if FL_PROG_WT_STORES
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+#else
+  *(gf4w_t*)(p) = t;
+#endif
+}
+
+// A job descriptor is read from the LDS copy into scalar registers (every field is wave-uniform); unused fields fold away.
+// (field by field, typed: a punned word copy keeps the struct in scratch memory)
+// ONE ds_read: lane i fetches word i of the 60-word descriptor, fields are then picked with v_readlane.
+typedef const __attribute__((address_space(3))) int* lint_p;
+typedef int jobwords_t;
+__device__ __forceinline__ int ldsi(jobwords_t p, int word) { return __builtin_amdgcn_readlane(p, word); }
+__device__ __forceinline__ float ldsf(jobwords_t p, int word) { return __int_as_float(ldsi(p, word)); }
+__device__ __forceinline__ uint64_t ldsp(jobwords_t p, int word) {
+  return (uint64_t)(unsigned)ldsi(p, word) | ((uint64_t)(unsigned)ldsi(p, word + 1) << 32);
+}
+#define FL_JW(f) ((int)(offsetof(fl_pjob, f) / 4))
+__device__ __forceinline__ void load_job(const int* src /* LDS */, fl_pjob& d) {
+  static_assert(sizeof(fl_pjob) / 4 <= 64, "descriptor must fit one word per lane");
+  const int ln = threadIdx.x & 63;
+  const jobwords_t p = ((lint_p)src)[ln < (int)(sizeof(fl_pjob) / 4) ? ln : 0];
+#pragma unroll
+  for (int s = 0; s < FL_PROG_MAX_SEG; ++s) {
+    d.A[s] = ldsp(p, FL_JW(A) + 2 * s);
+    d.W[s] = ldsp(p, FL_JW(W) + 2 * s);
+    d.bias[s] = ldsp(p, FL_JW(bias) + 2 * s);
+    d.K[s] = ldsi(p, FL_JW(K) + s);
+    d.lda[s] = ldsi(p, FL_JW(lda) + s);
+    d.ldw[s] = ldsi(p, FL_JW(ldw) + s);
+    d.bias_scale[s] = ldsf(p, FL_JW(bias_scale) + s);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) d.aux[s] = ldsp(p, FL_JW(aux) + 2 * s);
+  d.R = ldsp(p, FL_JW(R));
+  d.C = ldsp(p, FL_JW(C));
+  d.mask = ldsp(p, FL_JW(mask));
+  d.gate = ldsp(p, FL_JW(gate));
+  d.kind = ldsi(p, FL_JW(kind));
+  d.M = ldsi(p, FL_JW(M));
+  d.N = ldsi(p, FL_JW(N));
+  d.nseg = ldsi(p, FL_JW(nseg));
+  d.ldr = ldsi(p, FL_JW(ldr));
+  d.ldc = ldsi(p, FL_JW(ldc));
+  d.act = ldsi(p, FL_JW(act));
+  d.mask_group = ldsi(p, FL_JW(mask_group));
+  d.tile_begin = ldsi(p, FL_JW(tile_begin));
+  d.ntiles = ldsi(p, FL_JW(ntiles));
+  d.eps = ldsf(p, FL_JW(eps));
+  d.eps2 = ldsf(p, FL_JW(eps2));
+}
+
+// ---------------------------------------------------------------------------------------------- GEMM tile
+struct Stage {
+  f32x4v a[8], w[8];
+};
+
+__device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int lt, const ProgIO& io, float* smem) {
+  const int nct = jb.N / TS, nrt = (jb.M + TS - 1) / TS;
+  int ct, rt;
+  if ((nct & 7) == 0) {  // tile lt runs on XCD lt%8 (round-robin block placement): keep a weight column block on one XCD
+    const int x = lt & 7, j = lt >> 3, jc = j / nrt;
+    ct = x + 8 * jc;
+    rt = j - jc * nrt;
+  } else {
+    ct = lt / nrt;
+    rt = lt - ct * nrt;
+  }
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+  const int kq4 = lane * 4;  // this thread's k offset inside a chunk row (a wave covers one whole 256-wide row slice)
+
+  // chunk bookkeeping (all scalar): segment s owns chunks [cb_s, cb_{s+1})
+  const float* A0 = rp(jb.A[0], io);
+  const float* W0 = rp(jb.W[0], io);
+  const float *A1 = A0, *A2 = A0, *W1 = W0, *W2 = W0;
+  const int c1 = (jb.K[0] + KC - 1) / KC;
+  int c2 = c1, nC = c1;
+  if (jb.nseg > 1) {
+    A1 = rp(jb.A[1], io);
+    W1 = rp(jb.W[1], io);
+    c2 = nC = c1 + (jb.K[1] + KC - 1) / KC;
+  }
+  if (jb.nseg > 2) {
+    A2 = rp(jb.A[2], io);
+    W2 = rp(jb.W[2], io);
+    nC = c2 + (jb.K[2] + KC - 1) / KC;
+  }
+  const int K0 = jb.K[0], K1 = jb.K[1], K2 = jb.K[2];  // scalars: a select between array elements would pin jb in memory
+  const int lda0 = jb.lda[0], lda1 = jb.lda[1], lda2 = jb.lda[2];
+  const int ldw0 = jb.ldw[0], ldw1 = jb.ldw[1], ldw2 = jb.ldw[2];
+  const int r0 = rt * TS + w, n0 = ct * TS + w;  // this thread loads rows r0 + 4i (A) and n0 + 4i (W), i < 8
+  const int Mm1 = jb.M - 1;
+
+  // global -> registers for chunk c (clamped: a surplus stage re-reads the last chunk and is never consumed);
+  // returns whether this thread's 16-byte column lies inside the chunk's valid k range
+#define FL_ISSUE(RS, cidx, okvar)                                                                  \
+  do {                                                                                             \
+    int c_ = (cidx);                                                                               \
+    c_ = c_ < nC ? c_ : nC - 1;                                                                    \
+    const bool s1_ = c_ >= c1, s2_ = c_ >= c2;                                                     \
+    const float* Ab_ = s2_ ? A2 : (s1_ ? A1 : A0);                                                 \
+    const float* Wb_ = s2_ ? W2 : (s1_ ? W1 : W0);                                                 \
+    const int lda_ = s2_ ? lda2 : (s1_ ? lda1 : lda0);                                             \
+    const int ldw_ = s2_ ? ldw2 : (s1_ ? ldw1 : ldw0);                                             \
+    const int Ks_ = s2_ ? K2 : (s1_ ? K1 : K0);                                                    \
+    const int kk_ = (c_ - (s2_ ? c2 : (s1_ ? c1 : 0))) * KC;                                       \
+    okvar = kk_ + kq4 < Ks_;                                                                       \
+    const int kcol_ = okvar ? kk_ + kq4 : kk_;                                                     \
+    /* 32-bit element offsets from a scalar base (validated: rows*ld < 2^30): full-rate 24-bit multiplies */       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                             \
+      int ar_ = r0 + 4 * i_;                                                                       \
+      ar_ = ar_ < Mm1 ? ar_ : Mm1;                                                                 \
+      RS.a[i_] = ld4gv(Ab_ + (size_t)(__umul24((unsigned)ar_, (unsigned)lda_) + (unsigned)kcol_)); \
+    }                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                               \
+      RS.w[i_] = ld4gv(Wb_ + (size_t)(__umul24((unsigned)(n0 + 4 * i_), (unsigned)ldw_) + (unsigned)kcol_)); \
+  } while (0)
+
+  // registers -> LDS stage (row images [32][LDK] for A, then W); out-of-range columns become zeros
+#define FL_PARK(RS, okvar, st)                                                                     \
+  do {                                                                                             \
+    float* La_ = smem + (st) * STAGE + w * LDK + kq4;                                              \
+    float* Lw_ = La_ + TS * LDK;                                                                   \
+    const f32x4v z_ = {0.f, 0.f, 0.f, 0.f};                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                             \
+      *(lf4_t*)(La_ + 4 * i_ * LDK) = okvar ? RS.a[i_] : z_;                                       \
+      *(lf4_t*)(Lw_ + 4 * i_ * LDK) = okvar ? RS.w[i_] : z_;                                       \
+    }                                                                                              \
+  } while (0)
+
+  // each wave contracts its 64-wide k slice of the parked chunk: 2 x (8 ds_read_b128 + 16 MFMA)
+#define FL_CONTRACT(st)                                                                            \
+  do {                                                                                             \
+    const float* Fa_ = smem + (st) * STAGE + lr * LDK + 64 * w + 16 * lh;                          \
+    const float* Fw_ = Fa_ + TS * LDK;                                                             \
+    f32x4v fa_[8], fw_[8]; /* all 16 fragment reads in flight before the first MFMA */            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                             \
+      fa_[q_] = *(const lf4_t*)(Fa_ + 32 * (q_ >> 2) + 4 * (q_ & 3));                              \
+      fw_[q_] = *(const lf4_t*)(Fw_ + 32 * (q_ >> 2) + 4 * (q_ & 3));                              \
+    }                                                                                              \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                             \
+      _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                             \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[q_][e_], fw_[q_][e_], acc, 0, 0, 0);        \
+    }                                                                                              \
+  } while (0)
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // epilogue operands are requested first: they ride along with the chunk loads instead of costing a memory round
+  // trip (about 1 us here) after the contraction
+  const int er = threadIdx.x >> 3, ec = (threadIdx.x & 7) * 4;
+  const int gr = rt * TS + er, gc = ct * TS + ec;
+  const int grc = gr < jb.M ? gr : jb.M - 1;
+  float4 e_b[FL_PROG_MAX_SEG], e_r = make_float4(0.f, 0.f, 0.f, 0.f);
+  float e_gate = 0.f, e_m = 1.f;
+#pragma unroll
+  for (int s = 0; s < FL_PROG_MAX_SEG; ++s) {
+    e_b[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (jb.bias[s]) e_b[s] = ld4g(rp(jb.bias[s], io) + gc);
+  }
+  if (jb.gate) e_gate = ld1g(rp(jb.gate, io));
+  if (jb.mask) e_m = ld1g(rp(jb.mask, io) + (long long)grc * (jb.N / jb.mask_group) + gc / jb.mask_group);
+  if (jb.R) e_r = ld4g(rp(jb.R, io) + (long long)grc * jb.ldr + gc);
+  Stage R0, R1;
+  bool ok0, ok1;
+  FL_STAMP(7);
+  FL_ISSUE(R0, 0, ok0);
+  FL_ISSUE(R1, 1, ok1);
+  FL_STAMP(8);
+  for (int c = 0; c < nC; c += 2) {
+    FL_PARK(R0, ok0, 0);
+    FL_ISSUE(R0, c + 2, ok0);
+    __syncthreads();
+    FL_CONTRACT(0);
+    const bool more = c + 1 < nC;  // block-uniform
+    if (more) FL_PARK(R1, ok1, 1);
+    FL_ISSUE(R1, c + 3, ok1);
+    __syncthreads();
+    if (more) FL_CONTRACT(1);
+  }
+#undef FL_ISSUE
+#undef FL_PARK
+#undef FL_CONTRACT
+  FL_STAMP(1);
+
+  // meet in LDS: sm[w][row][col] (aliases stage 0; the loop's last barrier precedes every wave's last stage-0 read
+  // only when nC is even, so fence once more); C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  __syncthreads();
+  float* mine = smem + w * (TS * SLD);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) *(lf1_t*)(mine + ((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + lr) = acc[r];
+  __syncthreads();
+  const float* s0 = smem + er * SLD + ec;
+  f32x4v vv = *(const lf4_t*)(s0);
+#pragma unroll
+  for (int k = 1; k < 4; ++k) vv += *(const lf4_t*)(s0 + k * (TS * SLD));
+  float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+  if (gr < jb.M) {
+    const float gmul = jb.gate ? 1.f + fl::sigmoid_acc(e_gate) : 1.f;
+#pragma unroll
+    for (int s = 0; s < FL_PROG_MAX_SEG; ++s) {
+      if (jb.bias[s]) {
+        const float sc = jb.bias_scale[s] * gmul;
+        v.x += sc * e_b[s].x; v.y += sc * e_b[s].y; v.z += sc * e_b[s].z; v.w += sc * e_b[s].w;
+      }
+    }
+    v.x = fl::apply_act(v.x, jb.act, 0.f);
+    v.y = fl::apply_act(v.y, jb.act, 0.f);
+    v.z = fl::apply_act(v.z, jb.act, 0.f);
+    v.w = fl::apply_act(v.w, jb.act, 0.f);
+    if (jb.mask) {
+      v.x *= e_m; v.y *= e_m; v.z *= e_m; v.w *= e_m;
+    }
+    if (jb.R) {
+      v.x += e_r.x; v.y += e_r.y; v.z += e_r.z; v.w += e_r.w;
+    }
+    st4g(wp(jb.C, io) + (long long)gr * jb.ldc + gc, v);
+  }
+  __syncthreads();  // the partial tiles alias stage 0 of the next tile
+}
+
+// Row LayerNorm (+mask, act, residual, gated extra) and an optional second LayerNorm of the result; one wave per row.
+__device__ __forceinline__ void rownorm_tile(const fl_pjob& jb, int lt, const ProgIO& io) {
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int row = lt * 4 + w;
+  if (row >= jb.M) return;
+  const int D = jb.N, nv = D >> 8;  // float4 per lane (D % 256 == 0, D <= 1024)
+  const float* x = rp(jb.A[0], io) + (long long)row * jb.lda[0];
+  float4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      v[i] = ld4g(x + (i * 64 + lane) * 4);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float m = fl::wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      const float a = v[i].x - m, b = v[i].y - m, c = v[i].z - m, d = v[i].w - m;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float r = 1.0f / sqrtf(fl::wave_sum(q) / D + jb.eps);
+  const float* w1 = rp(jb.W[0], io);
+  const float* b1 = rp(jb.bias[0], io);
+  const float* mk = jb.mask ? rp(jb.mask, io) + (long long)row * D : nullptr;
+  const float* R = jb.R ? rp(jb.R, io) + (long long)row * jb.ldr : nullptr;
+  const float* gx = jb.gate ? rp(jb.aux[1], io) + (long long)row * jb.lda[1] : nullptr;
+  const float sg = jb.gate ? fl::sigmoid_acc(ld1g(rp(jb.gate, io))) : 0.f;
+  float* y1 = jb.C ? wp(jb.C, io) + (long long)row * jb.ldc : nullptr;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      const int o = (i * 64 + lane) * 4;
+      const float4 ww = ld4g(w1 + o), bb = ld4g(b1 + o);
+      float4 y;
+      y.x = (v[i].x - m) * r * ww.x + bb.x;
+      y.y = (v[i].y - m) * r * ww.y + bb.y;
+      y.z = (v[i].z - m) * r * ww.z + bb.z;
+      y.w = (v[i].w - m) * r * ww.w + bb.w;
+      if (mk) {
+        const float4 k = ld4g(mk + o);
+        y.x *= k.x; y.y *= k.y; y.z *= k.z; y.w *= k.w;
+      }
+      y.x = fl::apply_act(y.x, jb.act, 0.f);
+      y.y = fl::apply_act(y.y, jb.act, 0.f);
+      y.z = fl::apply_act(y.z, jb.act, 0.f);
+      y.w = fl::apply_act(y.w, jb.act, 0.f);
+      if (R) {
+        const float4 k = ld4g(R + o);
+        y.x += k.x; y.y += k.y; y.z += k.z; y.w += k.w;
+      }
+      if (gx) {
+        const float4 k = ld4g(gx + o);
+        y.x += sg * k.x; y.y += sg * k.y; y.z += sg * k.z; y.w += sg * k.w;
+      }
+      if (y1) st4g(y1 + o, y);
+      v[i] = y;
+      s2 += (y.x + y.y) + (y.z + y.w);
+    }
+  }
+  if (!jb.W[1]) return;
+  const float m2 = fl::wave_sum(s2) / D;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      const float a = v[i].x - m2, b = v[i].y - m2, c = v[i].z - m2, d = v[i].w - m2;
+      q2 += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float r2 = 1.0f / sqrtf(fl::wave_sum(q2) / D + jb.eps2);
+  const float* w2 = rp(jb.W[1], io);
+  const float* b2 = rp(jb.bias[1], io);
+  float* y2 = wp(jb.aux[0], io) + (long long)row * jb.ldc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      const int o = (i * 64 + lane) * 4;
+      const float4 ww = ld4g(w2 + o), bb = ld4g(b2 + o);
+      float4 y;
+      y.x = (v[i].x - m2) * r2 * ww.x + bb.x;
+      y.y = (v[i].y - m2) * r2 * ww.y + bb.y;
+      y.z = (v[i].z - m2) * r2 * ww.z + bb.z;
+      y.w = (v[i].w - m2) * r2 * ww.w + bb.w;
+      st4g(y2 + o, y);
+    }
+  }
+}
+
+__device__ __forceinline__ void sinusoid_tile(const fl_pjob& jb, int lt, const ProgIO& io) {
+  const int half = jb.N >> 1;
+  const int i = lt * 256 + threadIdx.x;
+  if (i >= jb.M * half) return;
+  const int b = i / half, j = i - b * half;
+  const long long* t = reinterpret_cast<const long long*>(rp(jb.A[0], io));
+  const float a = (float)ldi64g(t + (long long)b * jb.lda[0]) * ld1g(rp(jb.W[0], io) + j);
+  float* out = wp(jb.C, io) + (long long)b * jb.ldc;
+  st1g(out + j, sinf(a));
+  st1g(out + half + j, cosf(a));
+}
+
+__device__ __forceinline__ void gather_tile(const fl_pjob& jb, int lt, const ProgIO& io) {
+  const int i = (lt * 256 + threadIdx.x) * 4;
+  if (i >= jb.M * jb.N) return;
+  const int b = i / jb.N, d = i - b * jb.N;
+  const long long* idx = reinterpret_cast<const long long*>(rp(jb.W[0], io));
+  const float4 v = ld4g(rp(jb.A[0], io) + ldi64g(idx + b) * jb.lda[0] + d);
+  st4g(wp(jb.C, io) + (long long)b * jb.ldc + d, v);
+}
+
+// Device-wide barrier for a fully resident grid. Arrival counters sync[g*CTR_STRIDE] (g = block & 7; monotone over the
+// run), departures sync[NCTR*CTR_STRIDE], abort flag sync[NCTR*CTR_STRIDE + 16]. Returns false if the run is dead
+// (timeout here or in another block): every wave then leaves.
+__device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, bool acquire, int* s_ok) {
+#if FL_PROG_WT_STORES
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // asm stores are invisible to the compiler's counters
+#endif
+  __syncthreads();  // every wave's stores have left the CU (s_waitcnt vmcnt(0) precedes s_barrier)
+  if (threadIdx.x == 0) {
+    // ONE release per block: write the XCD's dirty L2 lines back (the block's stores are in L2 by now), then arrive.
+    // Polling is relaxed (plain sc1 loads): an acquire per poll would invalidate the L2 on every iteration.
+    FL_STAMP(3);
+#if !FL_PROG_WT_STORES
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+    FL_STAMP(4);
+    __hip_atomic_fetch_add(&sync[(blockIdx.x & (NCTR - 1)) * CTR_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    FL_STAMP(5);
+    unsigned spins = 0;
+    int ok = 1;
+    for (;;) {
+      unsigned tot = 0;
+#pragma unroll
+      for (int g = 0; g < NCTR; ++g) tot += __hip_atomic_load(&sync[g * CTR_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tot >= target) break;
+      __builtin_amdgcn_s_sleep(1);
+      ++spins;
+      if ((spins & 255u) == 0 && (spins > SPIN_LIMIT || __hip_atomic_load(&sync[NCTR * CTR_STRIDE + 16], __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        __hip_atomic_store(&sync[NCTR * CTR_STRIDE + 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    // The invalidating acquire is only needed when the next phase re-reads a buffer that was overwritten after an
+    // earlier read in this launch (stale L1/L2 lines): the program builder knows; a launch starts with clean caches.
+    if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_ok = ok;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+__global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __restrict__ phases, const fl_pjob* __restrict__ jobs,
+                                                         int nphases, int njobs, const ProgIO io, unsigned* sync) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_ok;
+  // the program lives in LDS for the whole run
+  int* lprog = reinterpret_cast<int*>(smem + 2 * STAGE);
+  {
+    const int nph_w = nphases * (int)(sizeof(fl_pphase) / 4);
+    const int* gp = reinterpret_cast<const int*>(phases);
+    for (int i = threadIdx.x; i < nph_w; i += 256) ((__attribute__((address_space(3))) int*)lprog)[i] = gp[i];
+    // jobs: 64-bit words; the leading pointer fields that name an io slot (1..FL_PROG_MAX_IO) are bound here, once,
+    // so that no tile ever waits on a kernel-argument fetch
+    constexpr int JQ = sizeof(fl_pjob) / 8, PTRQ = offsetof(fl_pjob, kind) / 8;
+    const unsigned long long* gj = reinterpret_cast<const unsigned long long*>(jobs);
+    __attribute__((address_space(3))) unsigned long long* lj = (__attribute__((address_space(3))) unsigned long long*)(lprog + nph_w);
+    for (int i = threadIdx.x; i < njobs * JQ; i += 256) {
+      unsigned long long v = gj[i];
+      if (i % JQ < PTRQ && v >= 1 && v <= FL_PROG_MAX_IO) v = reinterpret_cast<unsigned long long>(io.p[v - 1]);
+      lj[i] = v;
+    }
+    __syncthreads();
+  }
+  const int* lph = lprog;
+  const int* ljb = lprog + nphases * (int)(sizeof(fl_pphase) / 4);
+  constexpr int JW = sizeof(fl_pjob) / 4;
+  constexpr int TB_OFF = offsetof(fl_pjob, tile_begin) / 4;
+  const unsigned G = gridDim.x;
+  bool alive = true;
+  for (int p = 0; p < nphases && alive; ++p) {
+#if FL_PROG_TRACE
+    if (threadIdx.x == 0) {
+      g_trace = (unsigned long long*)io.p[15];
+      g_trace_phases = nphases;
+      g_trace_p = p;
+    }
+#endif
+    FL_STAMP(0);
+#if FL_PROG_TRACE
+    if (threadIdx.x == 0 && g_trace) g_trace[((size_t)blockIdx.x * g_trace_phases + g_trace_p) * 12 + 11] = clock64();
+#endif
+    const __attribute__((address_space(3))) int* ph = (const __attribute__((address_space(3))) int*)(lph + 4 * p);
+    const int job_begin = __builtin_amdgcn_readfirstlane(ph[0]), job_end = __builtin_amdgcn_readfirstlane(ph[1]);
+    const int ntiles = __builtin_amdgcn_readfirstlane(ph[2]);
+    for (int t = blockIdx.x; t < ntiles; t += G) {
+      int j = job_begin;
+      while (j + 1 < job_end &&
+             t >= __builtin_amdgcn_readfirstlane(((const __attribute__((address_space(3))) int*)ljb)[(j + 1) * JW + TB_OFF]))
+        ++j;
+      fl_pjob jb;
+      load_job(ljb + j * JW, jb);
+      const int lt = t - jb.tile_begin;
+      switch (jb.kind) {
+        case FL_PJOB_GEMM: gemm_tile(jb, lt, io, smem); break;
+        case FL_PJOB_ROWNORM: rownorm_tile(jb, lt, io); break;
+        case FL_PJOB_SINUSOID: sinusoid_tile(jb, lt, io); break;
+        case FL_PJOB_GATHER: gather_tile(jb, lt, io); break;
+        default: break;
+      }
+    }
+    FL_STAMP(2);
+#if FL_PROG_TRACE
+    if (threadIdx.x == 0 && g_trace) {
+      unsigned long long* e = &g_trace[((size_t)blockIdx.x * g_trace_phases + g_trace_p) * 12 + 11];
+      *e = clock64() - *e;  // core-clock cycles spent on this phase's tiles
+    }
+#endif
+    if (p + 1 < nphases) {
+      const int next_flags = __builtin_amdgcn_readfirstlane(((const __attribute__((address_space(3))) int*)lph)[4 * (p + 1) + 3]);
+      alive = grid_barrier(sync, (unsigned)(p + 1) * G, (next_flags & FL_PPHASE_ACQUIRE) != 0, &s_ok);
+    }
+    FL_STAMP(6);
+  }
+  // self-cleaning: the last block to leave re-arms the counters for the next run (not after an abort)
+  __syncthreads();
+  if (threadIdx.x == 0 && alive) {
+    const unsigned old = __hip_atomic_fetch_add(&sync[NCTR * CTR_STRIDE], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == G - 1) {
+#pragma unroll
+      for (int g = 0; g < NCTR; ++g) __hip_atomic_store(&sync[g * CTR_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync[NCTR * CTR_STRIDE], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+int device_cus() {
+  static int cus = 0;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  });
+  return cus;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fl_program_job_bytes(void) { return (int)sizeof(fl_pjob); }
+int fl_program_phase_bytes(void) { return (int)sizeof(fl_pphase); }
+
+int fl_program_job_tiles(const void* job) {
+  FL_REQUIRE(job, "fl_program_job_tiles: null job");
+  const fl_pjob& j = *reinterpret_cast<const fl_pjob*>(job);
+  FL_REQUIRE(j.M >= 1 && j.N >= 1 && j.C, "program job: M=%d N=%d C=%llu", j.M, j.N, (unsigned long long)j.C);
+  switch (j.kind) {
+    case FL_PJOB_GEMM: {
+      FL_REQUIRE(j.nseg >= 1 && j.nseg <= FL_PROG_MAX_SEG && j.N % TS == 0 && j.ldc % 4 == 0, "program GEMM: nseg=%d N=%d ldc=%d",
+                 j.nseg, j.N, j.ldc);
+      for (int s = 0; s < j.nseg; ++s)
+        FL_REQUIRE(j.A[s] && j.W[s] && j.K[s] >= 4 && j.K[s] % 4 == 0 && j.lda[s] % 4 == 0 && j.ldw[s] % 4 == 0 && j.ldw[s] >= j.K[s],
+                   "program GEMM segment %d: K=%d lda=%d ldw=%d", s, j.K[s], j.lda[s], j.ldw[s]);
+      for (int s = 0; s < j.nseg; ++s)  // operands are addressed with 32-bit element offsets and 24-bit multiplies
+        FL_REQUIRE(j.M < (1 << 24) && j.N < (1 << 24) && j.lda[s] >= 0 && j.lda[s] < (1 << 24) && j.ldw[s] < (1 << 24) &&
+                       (long long)j.M * j.lda[s] < (1ll << 30) && (long long)j.N * j.ldw[s] < (1ll << 30),
+                   "program GEMM segment %d: operand too large for 32-bit offsets", s);
+      FL_REQUIRE(!j.R || j.ldr % 4 == 0, "program GEMM: ldr=%d", j.ldr);
+      FL_REQUIRE(!j.mask || (j.mask_group >= 4 && j.mask_group % 4 == 0 && j.N % j.mask_group == 0), "program GEMM: mask_group=%d",
+                 j.mask_group);
+      return ((j.M + TS - 1) / TS) * (j.N / TS);
+    }
+    case FL_PJOB_ROWNORM:
+      FL_REQUIRE(j.A[0] && j.W[0] && j.bias[0] && j.N % 256 == 0 && j.N <= 1024 && j.lda[0] % 4 == 0 && j.ldc % 4 == 0,
+                 "program ROWNORM: N=%d lda=%d ldc=%d", j.N, j.lda[0], j.ldc);
+      FL_REQUIRE(!j.W[1] || (j.bias[1] && j.aux[0]), "program ROWNORM: second norm needs bias[1] and aux[0]");
+      FL_REQUIRE(!j.gate || (j.aux[1] && j.lda[1] % 4 == 0), "program ROWNORM: gate needs aux[1]");
+      return (j.M + 3) / 4;
+    case FL_PJOB_SINUSOID:
+      FL_REQUIRE(j.A[0] && j.W[0] && j.N % 2 == 0, "program SINUSOID: N=%d", j.N);
+      return (j.M * (j.N / 2) + 255) / 256;
+    case FL_PJOB_GATHER:
+      FL_REQUIRE(j.A[0] && j.W[0] && j.N % 4 == 0 && j.lda[0] % 4 == 0 && j.ldc % 4 == 0, "program GATHER: N=%d", j.N);
+      return (j.M * j.N / 4 + 255) / 256;
+    default:
+      fl::set_error("program job: unknown kind %d", j.kind);
+      return FL_ERR_BAD_ARG;
+  }
+}
+
+int fl_program_sync_bytes(void) { return SYNC_UINTS * 4; }
+
+int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_jobs, const void* const* io, int n_io,
+                   void* sync, int max_blocks, fl_stream_t stream) {
+  FL_REQUIRE(phases && jobs && sync && n_phases >= 1 && n_jobs >= 1 && n_io >= 0 && n_io <= FL_PROG_MAX_IO && (n_io == 0 || io),
+             "fl_program_run: bad args (n_phases=%d n_jobs=%d n_io=%d)", n_phases, n_jobs, n_io);
+  FL_REQUIRE((size_t)n_phases * sizeof(fl_pphase) + (size_t)n_jobs * sizeof(fl_pjob) <= (size_t)PROG_LDS_BYTES,
+             "fl_program_run: program too large for its LDS copy (%d phases, %d jobs; limit %d bytes)", n_phases, n_jobs,
+             PROG_LDS_BYTES);
+  ProgIO pio;
+  for (int i = 0; i < FL_PROG_MAX_IO; ++i) pio.p[i] = i < n_io ? io[i] : nullptr;
+  for (int i = 0; i < n_io; ++i)
+    FL_REQUIRE((reinterpret_cast<uintptr_t>(io[i]) & 15) == 0, "fl_program_run: io[%d] is not 16-byte aligned", i);
+  const int cus = device_cus();
+  if (cus <= 0) {
+    fl::set_error("fl_program_run: no device");
+    return FL_ERR_UNSUPPORTED;
+  }
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(program_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  });
+  // the barrier needs every block resident: one block per CU (157 KB of LDS each: a second block cannot join it)
+  int G = cus;
+  if (max_blocks > 0 && max_blocks < G) G = max_blocks;
+  hipLaunchKernelGGL(program_kernel, dim3(G), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const fl_pphase*>(phases), reinterpret_cast<const fl_pjob*>(jobs), n_phases, n_jobs, pio,
+                     reinterpret_cast<unsigned*>(sync));
+  return fl::check_launch("program_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+"""Host side of the persistent phase-program executor (include/flowers_hip.h, fl_program_run; csrc/program.hip).
+
+`ProgramBuilder` packs jobs/phases into the C structs of the header; `build_unet_program` lays the ConditionalUNet
+forward (v2:534-561) out as 26 phases: the per-layer GEMMs are fused by concatenating K (h + time_proj(tc) is one
+contraction, the `down` projection of layer i is folded into the first GEMM of layer i+1), both LayerNorms of a layer
+share one row phase, the attention head-dropout scale is an epilogue of the V projection. One launch replaces the 71
+kernels of engine.unet_forward.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib, ops
+
+GEMM, ROWNORM, SINUSOID, GATHER = 0, 1, 2, 3
+MAX_IO = 16
+
+JOB_DTYPE = np.dtype([
+    ("A", "<u8", 3), ("W", "<u8", 3), ("bias", "<u8", 3), ("R", "<u8"), ("C", "<u8"), ("mask", "<u8"), ("gate", "<u8"),
+    ("aux", "<u8", 4), ("kind", "<i4"), ("M", "<i4"), ("N", "<i4"), ("nseg", "<i4"), ("K", "<i4", 3), ("lda", "<i4", 3),
+    ("ldw", "<i4", 3), ("ldr", "<i4"), ("ldc", "<i4"), ("act", "<i4"), ("mask_group", "<i4"), ("tile_begin", "<i4"),
+    ("ntiles", "<i4"), ("bias_scale", "<f4", 3), ("eps", "<f4"), ("eps2", "<f4"), ("pad_", "<i4", 2)])
+PHASE_DTYPE = np.dtype([("job_begin", "<i4"), ("job_end", "<i4"), ("ntiles", "<i4"), ("flags", "<i4")])
+PHASE_ACQUIRE = 1
+SYNC_ABORT_WORD = 8 * 1024 + 16
+
+
+class IO:
+    """Names slot `index` of the io array given to Program.run (a tensor that changes from call to call)."""
+
+    def __init__(self, index):
+        assert 0 <= index < MAX_IO
+        self.index = index
+
+
+def _ptr(x, offset_elems=0):
+    if x is None:
+        return 0
+    if isinstance(x, IO):
+        assert offset_elems == 0
+        return x.index + 1
+    if isinstance(x, tuple):  # (tensor, element offset)
+        return _ptr(x[0], x[1])
+    return x.data_ptr() + 4 * offset_elems
+
+
+class ProgramBuilder:
+    def __init__(self):
+        self._phases = [[]]
+        self._keep = []  # tensors whose storage the program points into
+
+    def _hold(self, *xs):
+        for x in xs:
+            if isinstance(x, tuple):
+                x = x[0]
+            if isinstance(x, torch.Tensor):
+                self._keep.append(x)
+
+    def barrier(self):
+        """Everything added afterwards may read what was added before."""
+        if self._phases[-1]:
+            self._phases.append([])
+
+    @staticmethod
+    def _key(x):
+        """Identity of the buffer behind a pointer argument (for the stale-cache analysis in finalize)."""
+        if x is None:
+            return None
+        if isinstance(x, IO):
+            return ("io", x.index)
+        if isinstance(x, tuple):
+            x = x[0]
+        return ("mem", x.untyped_storage().data_ptr())
+
+    def _add(self, job, reads, writes):
+        self._phases[-1].append((job, [self._key(r) for r in reads if r is not None],
+                                 [self._key(w) for w in writes if w is not None]))
+
+    def gemm(self, M, N, segs, C, ldc, biases=(), act=ops.ACT_NONE, R=None, ldr=0, mask=None, mask_group=0, gate=None):
+        """C[M,N] = epi(sum_s A_s W_s^T). segs: [(A, lda, K, W, ldw)]; biases: [(bias, scale)]."""
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"], j["nseg"] = GEMM, M, N, len(segs)
+        for s, (A, lda, K, W, ldw) in enumerate(segs):
+            j["A"][s], j["lda"][s], j["K"][s], j["W"][s], j["ldw"][s] = _ptr(A), lda, K, _ptr(W), ldw
+            self._hold(A, W)
+        for s, (b, sc) in enumerate(biases):
+            j["bias"][s], j["bias_scale"][s] = _ptr(b), sc
+            self._hold(b)
+        j["C"], j["ldc"], j["act"] = _ptr(C), ldc, act
+        j["R"], j["ldr"] = _ptr(R), ldr
+        j["mask"], j["mask_group"], j["gate"] = _ptr(mask), mask_group, _ptr(gate)
+        self._hold(C, R, mask, gate)
+        self._add(j, [a[0] for a in segs] + [R, mask], [C])
+
+    def rownorm(self, M, D, x, ldx, w, b, eps, C, ldc, act=ops.ACT_NONE, mask=None, R=None, ldr=0, w2=None, b2=None,
+                eps2=1e-5, C2=None, gate=None, gx=None, ldgx=0):
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = ROWNORM, M, D
+        j["A"][0], j["lda"][0], j["W"][0], j["bias"][0], j["eps"] = _ptr(x), ldx, _ptr(w), _ptr(b), eps
+        j["C"], j["ldc"], j["act"], j["mask"], j["R"], j["ldr"] = _ptr(C), ldc, act, _ptr(mask), _ptr(R), ldr
+        j["W"][1], j["bias"][1], j["eps2"], j["aux"][0] = _ptr(w2), _ptr(b2), eps2, _ptr(C2)
+        j["gate"], j["aux"][1], j["lda"][1] = _ptr(gate), _ptr(gx), ldgx
+        self._hold(x, w, b, C, mask, R, w2, b2, C2, gate, gx)
+        self._add(j, [x, mask, R, gx], [C, C2])
+
+    def sinusoid(self, M, N, t, t_stride, freqs, C, ldc):
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = SINUSOID, M, N
+        j["A"][0], j["lda"][0], j["W"][0], j["C"], j["ldc"] = _ptr(t), t_stride, _ptr(freqs), _ptr(C), ldc
+        self._hold(t, freqs, C)
+        self._add(j, [t], [C])
+
+    def gather(self, M, N, table, ld_table, idx, C, ldc):
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = GATHER, M, N
+        j["A"][0], j["lda"][0], j["W"][0], j["C"], j["ldc"] = _ptr(table), ld_table, _ptr(idx), _ptr(C), ldc
+        self._hold(table, idx, C)
+        self._add(j, [idx], [C])
+
+    def finalize(self, device):
+        L = lib.load()
+        assert JOB_DTYPE.itemsize == L.fl_program_job_bytes() and PHASE_DTYPE.itemsize == L.fl_program_phase_bytes(), \
+            "program struct packing differs from the library's"
+        phases = [p for p in self._phases if p]
+        jobs = []
+        ph = np.zeros(len(phases), PHASE_DTYPE)
+        max_tiles = 0
+        # A run starts with clean caches and the barrier only writes dirty lines back. A phase needs the invalidating
+        # acquire iff it reads a buffer that was overwritten after some block may have cached an older version of it.
+        cached, stale = set(), set()
+        for pi, p in enumerate(phases):
+            reads = set(k for _, r, _ in p for k in r)
+            if reads & stale:
+                ph[pi]["flags"] |= PHASE_ACQUIRE
+                cached, stale = set(), set()
+            for _, _, w in p:
+                stale |= set(w) & cached
+            cached |= reads
+            ph[pi]["job_begin"] = len(jobs)
+            t0 = 0
+            for j, _, _ in p:
+                buf = j.tobytes()
+                n = L.fl_program_job_tiles(ctypes.c_char_p(buf))
+                if n < 0:
+                    raise ValueError("program job rejected: %s" % lib.last_error())
+                j["tile_begin"], j["ntiles"] = t0, n
+                t0 += n
+                jobs.append(j)
+            ph[pi]["job_end"], ph[pi]["ntiles"] = len(jobs), t0
+            max_tiles = max(max_tiles, t0)
+        jobs_np = np.stack(jobs)
+        jobs_t = torch.from_numpy(np.frombuffer(jobs_np.tobytes(), dtype=np.uint8).copy()).to(device)
+        ph_t = torch.from_numpy(np.frombuffer(ph.tobytes(), dtype=np.uint8).copy()).to(device)
+        return Program(ph_t, jobs_t, len(phases), len(jobs), max_tiles, self._keep, device)
+
+
+class Program:
+    def __init__(self, phases, jobs, n_phases, n_jobs, max_tiles, keep, device):
+        self.phases, self.jobs, self.n_phases, self.n_jobs, self.max_tiles = phases, jobs, n_phases, n_jobs, max_tiles
+        self._keep = keep
+        self.sync = torch.zeros(lib.load().fl_program_sync_bytes() // 4, dtype=torch.int32, device=device)
+        self.max_blocks = 0  # 0 = one block per CU
+
+    def run(self, io):
+        """io: list of tensors bound to the IO slots. Enqueues one kernel on the current stream (graph-capturable)."""
+        arr = (ctypes.c_void_p * MAX_IO)(*[t.data_ptr() for t in io])
+        lib.call("fl_program_run", ctypes.c_void_p(self.phases.data_ptr()), ctypes.c_void_p(self.jobs.data_ptr()),
+                 self.n_phases, self.n_jobs, arr, len(io), ctypes.c_void_p(self.sync.data_ptr()), self.max_blocks,
+                 ops._stream())
+
+    def check(self):
+        """Synchronising health check: raises if a barrier timed out (and re-arms the counters)."""
+        if int(self.sync[SYNC_ABORT_WORD]) != 0:
+            self.sync.zero_()
+            raise RuntimeError("persistent program aborted: a device-wide barrier timed out (is another persistent "
+                               "program running on this device?)")
+
+
+# ------------------------------------------------------------------------------------------------ ConditionalUNet
+X, T, CLS, OUT, BM0, HM0, CE = 0, 1, 2, 3, 4, 8, 12  # IO slots
+
+
+class UNetProgram:
+    """The ConditionalUNet forward as one persistent launch. Built for a fixed (B, shared-t?, class?, masks?, ce given?)
+    signature; weights are referenced in place (rebuild if a parameter is re-allocated)."""
+
+    def __init__(self, un, B, device, shared_t=False, has_class=True, masks=False, ce_given=False):
+        self.un, self.B, self.key = un, B, self.weights_key(un)
+        self.shared_t, self.has_class, self.masks, self.ce_given = shared_t, has_class, masks, ce_given
+        d = lambda p: p.detach()
+        SW = ops.ACT_SWISH
+        f32 = dict(dtype=torch.float32, device=device)
+        E = un.time_emb_dim
+        Bt = 1 if shared_t else B
+        te_m, ce_m = un.time_emb, un.class_emb
+        H1 = te_m.lin1.weight.shape[0]
+        pb = ProgramBuilder()
+        feat = torch.empty(Bt, E, **f32)
+        te1a = torch.empty(Bt, H1, **f32)
+        te = torch.empty(Bt, E, **f32)
+        ldt = 0 if shared_t else 1      # row stride multiplier of the time tensors (one shared row: stride 0)
+        pb.sinusoid(Bt, E, IO(T), 1, un._freqs(device), feat, E)
+        if has_class and not ce_given:
+            emb = torch.empty(B, E, **f32)
+            ce1a = torch.empty(B, ce_m.lin1.weight.shape[0], **f32)
+            ce = torch.empty(B, E, **f32)
+            pb.gather(B, E, d(ce_m.embedding.weight), E, IO(CLS), emb, E)
+        pb.barrier()
+        pb.gemm(Bt, H1, [(feat, E, E, d(te_m.lin1.weight), E)], te1a, H1, [(d(te_m.lin1.bias), 1.0)], act=SW)
+        if has_class and not ce_given:
+            C1 = ce1a.shape[1]
+            pb.gemm(B, C1, [(emb, E, E, d(ce_m.lin1.weight), E)], ce1a, C1, [(d(ce_m.lin1.bias), 1.0)], act=SW)
+        pb.barrier()
+        pb.gemm(Bt, E, [(te1a, H1, H1, d(te_m.lin2.weight), H1)], te, E, [(d(te_m.lin2.bias), 1.0)])
+        if has_class:
+            tc = torch.empty(B, E, **f32)
+            if ce_given:
+                ce = IO(CE)
+                # tc = te (one row or per row) + ce
+                pb.gemm(B, E, [(te1a, H1 * ldt, H1, d(te_m.lin2.weight), H1)], tc, E, [(d(te_m.lin2.bias), 1.0)], R=ce, ldr=E)
+            else:
+                pb.gemm(B, E, [(ce1a, C1, C1, d(ce_m.lin2.weight), C1)], ce, E, [(d(ce_m.lin2.bias), 1.0)])
+                # te + ce as one contraction over [te1a | ce1a]  (W(te)+W(ce)+2b of v2:543-544 needs only the sum)
+                pb.gemm(B, E, [(te1a, H1 * ldt, H1, d(te_m.lin2.weight), H1), (ce1a, C1, C1, d(ce_m.lin2.weight), C1)], tc, E,
+                        [(d(te_m.lin2.bias), 1.0), (d(ce_m.lin2.bias), 1.0)])
+            tc_ld, tb = E, 2.0
+        else:
+            tc, tc_ld, tb = te, E * ldt, 1.0
+        pb.barrier()
+        prev, prev_ld, prev_w, prev_b = IO(X), un.latent_dim, d(un.latent_proj.weight), d(un.latent_proj.bias)
+        Kprev = un.latent_dim
+        self.ws = [feat, te1a, te, tc]
+        for i, (block, norm, down) in enumerate(un.layers):
+            lin, ln = block[0], block[1]
+            D = lin.weight.shape[0]
+            tp, att = un.time_projections[i], un.attention_layers[i]
+            h1, g, h2, hn, vm, h3 = (torch.empty(B, D, **f32) for _ in range(6))
+            self.ws += [h1, g, h2, hn, vm, h3]
+            pb.gemm(B, D, [(prev, prev_ld, Kprev, prev_w, Kprev), (tc, tc_ld, E, d(tp.weight), E)], h1, D,
+                    [(prev_b, 1.0), (d(tp.bias), tb)])
+            pb.barrier()
+            pb.gemm(B, D, [(h1, D, D, d(lin.weight), D)], g, D, [(d(lin.bias), 1.0)])
+            pb.barrier()
+            pb.rownorm(B, D, g, D, d(ln.weight), d(ln.bias), ln.eps, h2, D, act=SW, mask=IO(BM0 + i) if masks else None,
+                       R=h1, ldr=D, w2=d(norm.weight), b2=d(norm.bias), eps2=norm.eps, C2=hn)
+            pb.barrier()
+            wv = (d(att.in_proj_weight), 2 * D * D)
+            bv = (d(att.in_proj_bias), 2 * D)
+            pb.gemm(B, D, [(hn, D, D, wv, D)], vm, D, [(bv, 1.0)], mask=IO(HM0 + i) if masks else None,
+                    mask_group=D // att.num_heads)
+            pb.barrier()
+            pb.gemm(B, D, [(vm, D, D, d(att.out_proj.weight), D)], h3, D, [(d(att.out_proj.bias), 1.0)], R=h2, ldr=D)
+            pb.barrier()
+            prev, prev_ld, prev_w, prev_b, Kprev = h3, D, d(down.weight), d(down.bias), D
+        ft, fcp, fn, fin = un.final_time_proj, un.final_class_proj, un.final_norm, un.final
+        Dl = ft.weight.shape[0]
+        hpre, u = torch.empty(B, Dl, **f32), torch.empty(B, Dl, **f32)
+        self.ws += [hpre, u]
+        segs = [(prev, prev_ld, Kprev, prev_w, Kprev), (te, E * ldt, E, d(ft.weight), E)]
+        biases = [(prev_b, 1.0), (d(ft.bias), 1.0)]
+        if has_class:
+            segs.append((ce, E, E, d(fcp.weight), E))
+            biases.append((d(fcp.bias), 1.0))
+        pb.gemm(B, Dl, segs, hpre, Dl, biases)
+        pb.barrier()
+        rw = d(un.residual_weight)
+        # u = LN(h) + sigmoid(rw) * x ; out = final(u) + sigmoid(rw)*final.bias  ==  final(LN(h)) + sigmoid(rw)*final(x)  (v2:561)
+        pb.rownorm(B, Dl, hpre, Dl, d(fn.weight), d(fn.bias), fn.eps, u, Dl, gate=rw, gx=IO(X), ldgx=un.latent_dim)
+        pb.barrier()
+        pb.gemm(B, un.latent_dim, [(u, Dl, Dl, d(fin.weight), Dl)], IO(OUT), un.latent_dim, [(d(fin.bias), 1.0)], gate=rw)
+        self.prog = pb.finalize(device)
+        self._dummy = torch.zeros(4, **f32)
+
+    @staticmethod
+    def weights_key(un):
+        return tuple(p.data_ptr() for p in un.parameters())
+
+    def __call__(self, x, t, c=None, block_masks=None, head_masks=None, ce=None, out=None):
+        B = self.B
+        assert x.shape[0] == B and (t.numel() == (1 if self.shared_t else B))
+        if out is None:
+            out = torch.empty(B, self.un.latent_dim, dtype=torch.float32, device=x.device)
+        ops._chk(x, t, c, out, ce)
+        z = self._dummy
+        io = [z] * 13
+        io[X], io[T], io[OUT] = x, t, out
+        if self.has_class and not self.ce_given:
+            io[CLS] = c
+        if self.ce_given:
+            io[CE] = ce
+        if self.masks:
+            for i in range(4):
+                ops._chk(block_masks[i], head_masks[i])
+                io[BM0 + i], io[HM0 + i] = block_masks[i], head_masks[i]
+        self.prog.run(io)
+        return out

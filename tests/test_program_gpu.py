@@ -1,0 +1,181 @@
+"""Persistent phase-program executor (fl_program_run) — job-level parity against torch fp64 on CPU and the
+ConditionalUNet program against (a) the multi-kernel engine forward and (b) the CPU oracle. fp32 on the device;
+tolerances = fp32 re-association of K<=2304 contractions (stated per test)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oxford_102_flower_gan_vae_latent_diffusion_amd import engine, modules as M, ops, program as P  # noqa: E402
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, tol=2e-5, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = max(1.0, b.abs().max().item())
+    assert err <= tol * ref, "%s max err %.3e (ref max %.3e)" % (what, err, ref)
+
+
+def swish(v):
+    return v * torch.sigmoid(v)
+
+
+@pytest.mark.parametrize("Mrows", [256, 37, 1])
+def test_gemm_jobs(dev, Mrows):
+    """Three jobs in one phase + a dependent one: concatenated K, broadcast row (lda=0), bias scales, gate, act,
+    per-group column mask, residual, ragged row tile."""
+    B = Mrows
+    A0, A1, A2 = rnd(B, 256, seed=1), rnd(1, 512, seed=2), rnd(B, 96, seed=3)
+    W0, W1, W2 = rnd(512, 256, seed=4, scale=0.1), rnd(512, 512, seed=5, scale=0.1), rnd(512, 96, seed=6, scale=0.1)
+    b0, b1 = rnd(512, seed=7), rnd(512, seed=8)
+    R = rnd(B, 512, seed=9)
+    hm = (torch.rand(B, 8, generator=torch.Generator().manual_seed(10)) > 0.3).float() / 0.7
+    gate = torch.tensor([0.3])
+    Wn = rnd(64, 512, seed=11, scale=0.1)
+    d = lambda t: t.to(dev)
+    dA0, dA1, dA2, dW0, dW1, dW2, db0, db1, dR, dhm, dg, dWn = map(d, (A0, A1, A2, W0, W1, W2, b0, b1, R, hm, gate, Wn))
+    C0 = torch.empty(B, 512, device=dev)
+    C1 = torch.empty(B, 512, device=dev)
+    C2 = torch.empty(B, 64, device=dev)
+    pb = P.ProgramBuilder()
+    pb.gemm(B, 512, [(dA0, 256, 256, dW0, 256), (dA1, 0, 512, dW1, 512), (dA2, 96, 96, dW2, 96)], C0, 512,
+            [(db0, 1.0), (db1, 2.0)], act=ops.ACT_SWISH, R=dR, ldr=512, mask=dhm, mask_group=64)
+    pb.gemm(B, 512, [(P.IO(0), 256, 256, dW0, 256)], C1, 512, [(db0, 1.0)], gate=dg)
+    pb.barrier()
+    pb.gemm(B, 64, [(C0, 512, 512, dWn, 512)], C2, 64)
+    prog = pb.finalize(dev)
+    assert prog.n_phases == 2 and prog.n_jobs == 3
+    for _ in range(2):  # second run: the self-cleaning barrier counters
+        prog.run([dA0])
+    prog.check()
+    acc = A0.double() @ W0.double().t() + A1.double() @ W1.double().t() + A2.double() @ W2.double().t()
+    ref0 = swish(acc + b0.double() + 2 * b1.double()) * hm.double().repeat_interleave(64, 1) + R.double()
+    close(C0, ref0, 2e-5, "C0")
+    ref1 = A0.double() @ W0.double().t() + (1 + torch.sigmoid(gate.double())) * b0.double()
+    close(C1, ref1, 2e-5, "C1")
+    close(C2, ref0 @ Wn.double().t(), 3e-5, "C2")
+
+
+@pytest.mark.parametrize("D", [256, 512, 1024])
+def test_rownorm_job(dev, D):
+    B = 70
+    x, R, gx = rnd(B, D, seed=1, scale=2.0), rnd(B, D, seed=2), rnd(B, D, seed=3)
+    w1, b1, w2, b2 = rnd(D, seed=4), rnd(D, seed=5), rnd(D, seed=6), rnd(D, seed=7)
+    mask = (torch.rand(B, D, generator=torch.Generator().manual_seed(8)) > 0.3).float() / 0.7
+    gate = torch.tensor([-0.2])
+    d = lambda t: t.to(dev)
+    y1, y2, y3 = (torch.empty(B, D, device=dev) for _ in range(3))
+    pb = P.ProgramBuilder()
+    pb.rownorm(B, D, d(x), D, d(w1), d(b1), 1e-5, y1, D, act=ops.ACT_SWISH, mask=d(mask), R=d(R), ldr=D, w2=d(w2), b2=d(b2),
+               eps2=1e-5, C2=y2)
+    pb.rownorm(B, D, d(x), D, d(w1), d(b1), 1e-5, y3, D, gate=d(gate), gx=d(gx), ldgx=D)
+    prog = pb.finalize(dev)
+    prog.run([])
+    prog.check()
+    xd = x.double()
+    ln1 = F.layer_norm(xd, (D,), w1.double(), b1.double(), 1e-5)
+    r1 = swish(ln1 * mask.double()) + R.double()
+    close(y1, r1, 1e-5, "y1")
+    close(y2, F.layer_norm(r1, (D,), w2.double(), b2.double(), 1e-5), 2e-5, "y2")
+    close(y3, ln1 + torch.sigmoid(gate.double()) * gx.double(), 1e-5, "y3")
+
+
+def test_rewritten_buffer_gets_acquire(dev):
+    """read -> overwrite -> re-read of one buffer inside a run: the builder must flag the invalidating acquire
+    (without it a block could re-read its stale L2 copy of `a`)."""
+    import numpy as np
+    a0 = rnd(256, 256, seed=1)
+    w = rnd(256, 256, seed=2, scale=0.1)
+    a, c, wd = a0.to(dev), torch.empty(256, 256, device=dev), w.to(dev)
+    pb = P.ProgramBuilder()
+    pb.gemm(256, 256, [(a, 256, 256, wd, 256)], c, 256)
+    pb.barrier()
+    pb.gemm(256, 256, [(c, 256, 256, wd, 256)], a, 256)
+    pb.barrier()
+    pb.gemm(256, 256, [(a, 256, 256, wd, 256)], c, 256)
+    prog = pb.finalize(dev)
+    flags = np.frombuffer(prog.phases.cpu().numpy().tobytes(), dtype=P.PHASE_DTYPE)["flags"]
+    assert list(flags) == [0, 0, P.PHASE_ACQUIRE]
+    prog.run([])
+    prog.check()
+    wt = w.double().t()
+    close(c, a0.double() @ wt @ wt @ wt, 5e-5, "3 chained GEMMs with an in-run overwrite")
+
+
+def test_program_rejects_bad_shapes(dev):
+    pb = P.ProgramBuilder()
+    a, w, c = torch.zeros(8, 42, device=dev), torch.zeros(32, 42, device=dev), torch.zeros(8, 32, device=dev)
+    pb.gemm(8, 32, [(a, 42, 42, w, 42)], c, 32)  # K / leading dimensions not multiples of 4
+    with pytest.raises(ValueError):
+        pb.finalize(dev)
+
+
+def _unet(dev, seed=0):
+    torch.manual_seed(seed)
+    un = M.ConditionalUNet().to(dev)
+    with torch.no_grad():
+        for p in un.parameters():  # make every LayerNorm affine / bias / gate matter
+            if p.dim() <= 1:
+                p.add_(0.1 * torch.randn_like(p))
+    return un
+
+
+@pytest.mark.parametrize("B,shared_t,has_class,masks", [(256, False, True, False), (37, False, True, True),
+                                                        (64, True, False, False), (512, True, True, False)])
+def test_unet_program_vs_engine(dev, B, shared_t, has_class, masks):
+    un = _unet(dev).eval()
+    x = rnd(B, 256, seed=1).to(dev)
+    t = torch.randint(0, 1000, (1 if shared_t else B,), generator=torch.Generator().manual_seed(2)).to(dev)
+    c = torch.randint(0, 102, (B,), generator=torch.Generator().manual_seed(3)).to(dev) if has_class else None
+    bm = hm = None
+    if masks:
+        un.rng.manual_seed(5)
+        bm, hm = un.dropout_masks(B, dev)
+    with torch.no_grad():
+        ref, _ = engine.unet_forward(un, x, t, c, bm, hm)
+        up = P.UNetProgram(un, B, dev, shared_t=shared_t, has_class=has_class, masks=masks)
+        out = up(x, t, c, bm, hm)
+        out2 = up(x, t, c, bm, hm)
+    up.prog.check()
+    close(out, ref, 3e-5, "program vs engine")
+    assert torch.equal(out, out2), "persistent forward is not run-to-run deterministic"
+
+
+def test_unet_program_vs_oracle(dev):
+    """Same seeded weights on both sides (procedural init), per-sample t, class-conditional, eval mode."""
+    import json
+    import os
+    from oracle import procedural_init as pinit, v2_oracle as O
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sd = pinit.procedural_state_dict(json.load(open(os.path.join(G, "state_dict_shapes.json")))["unet"], 44)
+    un = M.ConditionalUNet().to(dev).eval()
+    un.load_state_dict(sd)
+    B = 48
+    x, t = rnd(B, 256, seed=11), torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(12))
+    c = torch.randint(0, 102, (B,), generator=torch.Generator().manual_seed(13))
+    ref = O.unet_forward(sd, x, t, c)
+    with torch.no_grad():
+        out = P.UNetProgram(un, B, dev)(x.to(dev), t.to(dev), c.to(dev))
+    close(out, ref, 3e-5, "program vs oracle")
+    mse = ((out.cpu() - ref) ** 2).mean().item()
+    assert mse <= 1e-4, "eps-MSE %.3e above the north-star bound" % mse
+
+
+def test_unet_program_ce_given(dev):
+    """Sampler form: one shared timestep, class path hoisted out of the loop (ce computed once)."""
+    un = _unet(dev, 3).eval()
+    B = 96
+    x = rnd(B, 256, seed=1).to(dev)
+    t = torch.tensor([437], device=dev)
+    c = (torch.arange(B) % 102).to(dev)
+    with torch.no_grad():
+        ref, _ = engine.unet_forward(un, x, t, c)
+        ce = un.class_emb(c)
+        out = P.UNetProgram(un, B, dev, shared_t=True, has_class=True, ce_given=True)(x, t, ce=ce)
+    close(out, ref, 3e-5, "ce_given")

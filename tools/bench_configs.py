@@ -43,8 +43,23 @@ def unet_fwd():
         with torch.cuda.graph(g):
             out = un(x, t, c)
         graph = timeit(g.replay, 200)
-    return dict(config="unet_fwd_b256", ms_eager=eager * 1e3, ms_graph=graph * 1e3, gflop=4.161,
-                tflops=4.161 / graph / 1e3, frac_fp32_mfma=4.161 / graph / 1e3 / PEAK)
+        # persistent phase program: ONE launch for the whole forward (program.py / csrc/program.hip)
+        from oxford_102_flower_gan_vae_latent_diffusion_amd import program as P
+        up = P.UNetProgram(un, B, dev)
+        o2 = up(x, t, c)
+        torch.cuda.synchronize()
+        up.prog.check()
+        err = (o2 - out).abs().max().item()
+        pers_eager = timeit(lambda: up(x, t, c, out=o2), 200)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            up(x, t, c, out=o2)
+        pers = timeit(g2.replay, 500)
+        up.prog.check()
+    return dict(config="unet_fwd_b256", ms_eager=eager * 1e3, ms_graph=graph * 1e3, ms_persistent=pers * 1e3,
+                ms_persistent_eager=pers_eager * 1e3, persistent_vs_multikernel_maxabs=err, gflop=4.161,
+                tflops=4.161 / pers / 1e3, frac_fp32_mfma=4.161 / pers / 1e3 / PEAK,
+                frac_fp32_mfma_multikernel=4.161 / graph / 1e3 / PEAK)
 
 
 def vaegan():

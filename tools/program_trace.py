@@ -1,0 +1,66 @@
+"""Per-phase timeline of the persistent U-Net forward (needs the -DFL_PROG_TRACE build of the library:
+FL_LIB_PATH=.../libflowers_tr.so python tools/program_trace.py). Stamps (100 MHz wall clock, thread 0 of each block):
+0 phase start, 1 last MFMA loop done (GEMM tiles), 2 tiles done, 3 barrier entered, 4 release fence done,
+5 arrive atomic returned, 6 barrier left."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M, ops, program as P  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+B = int(os.environ.get("B", "256"))
+un = M.ConditionalUNet().to(dev).eval()
+x = torch.randn(B, 256, device=dev)
+t = torch.randint(0, 1000, (B,), device=dev)
+c = torch.randint(0, 102, (B,), device=dev)
+up = P.UNetProgram(un, B, dev)
+nph = up.prog.n_phases
+G = torch.cuda.get_device_properties(0).multi_processor_count
+trace = torch.zeros(G * nph * 12, dtype=torch.int64, device=dev)
+out = torch.empty(B, 256, device=dev)
+
+
+def run():
+    io = [up._dummy] * 16
+    io[P.X], io[P.T], io[P.CLS], io[P.OUT] = x, t, c, out
+    io[15] = trace
+    up.prog.run(io)
+
+
+for _ in range(5):
+    run()
+torch.cuda.synchronize()
+tr = trace.view(G, nph, 12).cpu().double() * 0.01  # us
+t0 = tr[:, 0, 0].min()
+print("blocks %d phases %d; total %.1f us (first phase start -> last phase tiles done)" % (G, nph, tr[:, nph - 1, 2].max() - t0))
+print("%-5s %8s %8s | %8s %8s %8s %8s %8s | %s" % ("phase", "start", "len", "tiles", "mfma", "fence", "atomic", "spin", "busy blocks"))
+jobs_per_phase = up.prog.phases.cpu().view(torch.int32).view(-1, 4)
+for p in range(nph):
+    s = tr[:, p, 0]
+    busy = (tr[:, p, 1] > 0) if True else None
+    tiles_done = tr[:, p, 2]
+    ntiles = int(jobs_per_phase[p, 2])
+    act = slice(0, min(ntiles, G))
+    start = s.min() - t0
+    end = (tr[:, p, 6].max() if p + 1 < nph else tiles_done.max()) - t0
+    tile_t = (tiles_done[act] - s[act]).mean()
+    mf = (tr[act, p, 1] - s[act]).clamp(min=0).mean() if (tr[act, p, 1] > 0).any() else float("nan")
+    if p + 1 < nph:
+        fence = (tr[:, p, 4] - tr[:, p, 3]).mean()
+        atom = (tr[:, p, 5] - tr[:, p, 4]).mean()
+        spin = (tr[:, p, 6] - tr[:, p, 5]).mean()
+        lastarr = tr[:, p, 5].max() - t0
+    else:
+        fence = atom = spin = float("nan")
+    det = ""
+    if (tr[act, p, 7] > 0).any():
+        a = act
+        det = " ptrs %.2f issue %.2f loop %.2f epi %.2f" % ((tr[a, p, 7] - s[a]).mean(), (tr[a, p, 8] - tr[a, p, 7]).mean(),
+                                                          (tr[a, p, 1] - tr[a, p, 8]).mean(), (tr[a, p, 2] - tr[a, p, 1]).mean())
+    cyc = trace.view(G, nph, 12)[act, p, 11].double().cpu()
+    mhz = (cyc / (tiles_done[act] - s[act])).mean()
+    print("%-5d %8.2f %8.2f | %8.2f %8.2f %8.2f %8.2f %8.2f | %d tiles%s  clk %.0f MHz" % (p, start, end - start, tile_t, mf, fence, atom, spin, ntiles, det, mhz))
