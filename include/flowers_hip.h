@@ -270,12 +270,18 @@ int fl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float
  *                    if W[1]: aux[0] = LN(y1; W[1], bias[1], eps2).   N = row width, N % 256 == 0, N <= 1024.
  *   FL_PJOB_SINUSOID C[M,N] = [sin(t*f) | cos(t*f)], t = (int64*)A[0] with element stride lda[0], f = W[0] (N/2 freqs).
  *   FL_PJOB_GATHER   C[M,N] = table A[0] rows picked by (int64*)W[0].
+ *   FL_PJOB_PSAMPLE  the DDPM reverse update (v2:585-592) on C = A[0] = x_t (in place allowed), A[1] = eps_theta:
+ *                    x <- (x - (1-a_t)/sqrt(1-ab_t)*eps)/sqrt(a_t) + [t>0] sqrt(beta_t)*z, t = *(int64*)aux[2], tables
+ *                    W[0..2] = alpha, alpha_bar, beta; z = A[2] if given, else Philox4x32-10 N(0,1) with seed
+ *                    (K[0] | K[1]<<32) and counter *(int64*)aux[0] + i/4 (the stream fl_philox_fill would produce).
+ * GEMM jobs may pick bias[0] from a table: when aux[2] != 0 the row *(int64*)aux[2] of stride bias_row_stride is
+ * used (time-dependent terms of the sampler, precomputed for every timestep).
  * Pointer fields hold a device address, 0 (none), or a small integer 1..FL_PROG_MAX_IO naming slot (value-1) of the
  * `io` array handed to fl_program_run (inputs/outputs that change per call while the program stays resident).
  * ------------------------------------------------------------------------ */
 #define FL_PROG_MAX_IO 16
 #define FL_PROG_MAX_SEG 3
-enum { FL_PJOB_GEMM = 0, FL_PJOB_ROWNORM = 1, FL_PJOB_SINUSOID = 2, FL_PJOB_GATHER = 3 };
+enum { FL_PJOB_GEMM = 0, FL_PJOB_ROWNORM = 1, FL_PJOB_SINUSOID = 2, FL_PJOB_GATHER = 3, FL_PJOB_PSAMPLE = 4 };
 typedef struct fl_pjob {
   uint64_t A[FL_PROG_MAX_SEG], W[FL_PROG_MAX_SEG], bias[FL_PROG_MAX_SEG];
   uint64_t R, C, mask, gate;
@@ -286,8 +292,16 @@ typedef struct fl_pjob {
   int32_t tile_begin, ntiles; /* tiles of this job inside its phase: [tile_begin, tile_begin + ntiles) */
   float bias_scale[FL_PROG_MAX_SEG];
   float eps, eps2;
-  int32_t pad_[2];
+  int32_t bias_row_stride, pad_;
 } fl_pjob; /* 240 bytes, no implicit padding */
+/* Counters bumped once per run, after the last phase, by the last block to leave (the device-resident DDPM step
+ * counter in its int32 and int64 forms, the Philox offset): ptr == 0 entries are skipped. */
+typedef struct fl_program_post {
+  uint64_t ptr64[2];
+  int64_t delta64[2];
+  uint64_t ptr32;
+  int32_t delta32, pad_;
+} fl_program_post;
 #define FL_PPHASE_ACQUIRE 1 /* flags: invalidate L1/L2 before this phase (it re-reads a buffer that an earlier phase of
                               the same run overwrote AFTER some block had read it; a run starts with clean caches) */
 typedef struct fl_pphase {
@@ -296,7 +310,7 @@ typedef struct fl_pphase {
 /* sizeof(fl_pjob) / sizeof(fl_pphase) as compiled: the host-side builder asserts its packing against these */
 int fl_program_job_bytes(void);
 int fl_program_phase_bytes(void);
-/* tiles a job occupies (GEMM: ceil(M/32)*(N/32); ROWNORM: ceil(M/4); SINUSOID: ceil(M*N/2/256); GATHER: ceil(M*N/1024));
+/* tiles a job occupies (GEMM: ceil(M/32)*(N/32); ROWNORM: ceil(M/4); SINUSOID: ceil(M*N/2/256); GATHER, PSAMPLE: ceil(M*N/1024));
  * negative fl_status if the job violates the shape rules above. `job` is a HOST pointer. */
 int fl_program_job_tiles(const void* job);
 /* Bytes of the barrier area `sync` (arrival counters spread over memory channels, departures, abort flag). */
@@ -306,9 +320,9 @@ int fl_program_sync_bytes(void);
  * n_io device pointers (read at call time). `sync`: fl_program_sync_bytes() zeroed device bytes owned by the caller,
  * reused across runs (abort word != 0 afterwards: the run is void and the caller must zero `sync`). max_blocks: 0 =
  * one block per CU. Concurrent runs must not share `sync`; two programs running at once on one device may each wait
- * for CUs the other holds until the barrier timeout fires. */
+ * for CUs the other holds until the barrier timeout fires. `post`: HOST pointer to an fl_program_post, or NULL. */
 int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_jobs, const void* const* io, int n_io,
-                   void* sync, int max_blocks, fl_stream_t stream);
+                   void* sync, int max_blocks, const void* post, fl_stream_t stream);
 
 #ifdef __cplusplus
 }

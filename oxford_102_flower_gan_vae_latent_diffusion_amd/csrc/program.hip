@@ -19,6 +19,7 @@
 // write-back is needed; the invalidating acquire only where the program says a buffer is re-read after being re-written.
 // The program itself is copied to LDS once (a cold descriptor fetch costs 1-2.5 us per phase otherwise).
 #include <cstddef>
+#include <cstring>
 #include <mutex>
 
 #include "fl_common.h"
@@ -54,6 +55,7 @@ __shared__ int g_trace_phases, g_trace_p;
 
 struct ProgIO {
   const void* p[FL_PROG_MAX_IO];
+  fl_program_post post;
 };
 
 // io slots are bound when the program is copied to LDS (program_kernel): descriptors hold plain addresses here
@@ -139,6 +141,7 @@ __device__ __forceinline__ void load_job(const int* src /* LDS */, fl_pjob& d) {
   d.ntiles = ldsi(p, FL_JW(ntiles));
   d.eps = ldsf(p, FL_JW(eps));
   d.eps2 = ldsf(p, FL_JW(eps2));
+  d.bias_row_stride = ldsi(p, FL_JW(bias_row_stride));
 }
 
 // ---------------------------------------------------------------------------------------------- GEMM tile
@@ -249,7 +252,12 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int lt, const ProgI
 #pragma unroll
   for (int s = 0; s < FL_PROG_MAX_SEG; ++s) {
     e_b[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (jb.bias[s]) e_b[s] = ld4g(rp(jb.bias[s], io) + gc);
+    if (jb.bias[s]) {
+      const float* bp = rp(jb.bias[s], io) + gc;
+      if (s == 0 && jb.aux[2])  // row of a per-timestep table, picked by a device-resident index
+        bp += ldi64g(reinterpret_cast<const long long*>(rp(jb.aux[2], io))) * jb.bias_row_stride;
+      e_b[s] = ld4g(bp);
+    }
   }
   if (jb.gate) e_gate = ld1g(rp(jb.gate, io));
   if (jb.mask) e_m = ld1g(rp(jb.mask, io) + (long long)grc * (jb.N / jb.mask_group) + gc / jb.mask_group);
@@ -427,6 +435,59 @@ __device__ __forceinline__ void gather_tile(const fl_pjob& jb, int lt, const Pro
   st4g(wp(jb.C, io) + (long long)b * jb.ldc + d, v);
 }
 
+// ---- Philox4x32-10, the same stream as fl_philox_fill (elementwise.hip): 4 normals per counter -------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint64_t ctr) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const float u1 = u01(c[0]), u2 = u01(c[1]), u3 = u01(c[2]), u4 = u01(c[3]);
+  const float ra = sqrtf(-2.f * logf(u1)), rb = sqrtf(-2.f * logf(u3));
+  float s1, c1, s2, c2;
+  sincosf(6.283185307179586f * u2, &s1, &c1);
+  sincosf(6.283185307179586f * u4, &s2, &c2);
+  return make_float4(ra * c1, ra * s1, rb * c2, rb * s2);
+}
+
+// DDPM reverse update (v2:585-592; same arithmetic as p_sample_kernel in elementwise.hip), float4 per thread.
+__device__ __forceinline__ void psample_tile(const fl_pjob& jb, int lt, const ProgIO& io) {
+  const long long i4 = (long long)lt * 256 + threadIdx.x;  // float4 index == Philox counter offset
+  const long long n = (long long)jb.M * jb.N;
+  if (i4 * 4 >= n) return;
+  const int t = (int)ldi64g(reinterpret_cast<const long long*>(rp(jb.aux[2], io)));
+  const float a = ld1g(rp(jb.W[0], io) + t), ab = ld1g(rp(jb.W[1], io) + t), be = ld1g(rp(jb.W[2], io) + t);
+  const float coef = (1.f - a) / sqrtf(1.f - ab), sa = sqrtf(a), sg = sqrtf(be);
+  const float4 x = ld4g(rp(jb.A[0], io) + i4 * 4), e = ld4g(rp(jb.A[1], io) + i4 * 4);
+  float4 m;
+  m.x = (x.x - coef * e.x) / sa;
+  m.y = (x.y - coef * e.y) / sa;
+  m.z = (x.z - coef * e.z) / sa;
+  m.w = (x.w - coef * e.w) / sa;
+  if (t > 0) {
+    float4 z;
+    if (jb.A[2]) {
+      z = ld4g(rp(jb.A[2], io) + i4 * 4);
+    } else {
+      const uint64_t seed = (uint64_t)(unsigned)jb.K[0] | ((uint64_t)(unsigned)jb.K[1] << 32);
+      const uint64_t base = (uint64_t)ldi64g(reinterpret_cast<const long long*>(rp(jb.aux[0], io)));
+      z = philox_normal4(seed, base + (uint64_t)i4);
+    }
+    m.x += sg * z.x; m.y += sg * z.y; m.z += sg * z.z; m.w += sg * z.w;
+  }
+  st4g(wp(jb.C, io) + i4 * 4, m);
+}
+
 // Device-wide barrier for a fully resident grid. Arrival counters sync[g*CTR_STRIDE] (g = block & 7; monotone over the
 // run), departures sync[NCTR*CTR_STRIDE], abort flag sync[NCTR*CTR_STRIDE + 16]. Returns false if the run is dead
 // (timeout here or in another block): every wave then leaves.
@@ -526,6 +587,7 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
         case FL_PJOB_ROWNORM: rownorm_tile(jb, lt, io); break;
         case FL_PJOB_SINUSOID: sinusoid_tile(jb, lt, io); break;
         case FL_PJOB_GATHER: gather_tile(jb, lt, io); break;
+        case FL_PJOB_PSAMPLE: psample_tile(jb, lt, io); break;
         default: break;
       }
     }
@@ -550,6 +612,11 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
 #pragma unroll
       for (int g = 0; g < NCTR; ++g) __hip_atomic_store(&sync[g * CTR_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&sync[NCTR * CTR_STRIDE], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      // every block has finished every phase: bump the per-run counters (step counter, Philox offset)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (io.post.ptr64[k]) *(__attribute__((address_space(1))) long long*)(io.post.ptr64[k]) += io.post.delta64[k];
+      if (io.post.ptr32) *(__attribute__((address_space(1))) int*)(io.post.ptr32) += io.post.delta32;
     }
   }
 }
@@ -604,6 +671,11 @@ int fl_program_job_tiles(const void* job) {
     case FL_PJOB_GATHER:
       FL_REQUIRE(j.A[0] && j.W[0] && j.N % 4 == 0 && j.lda[0] % 4 == 0 && j.ldc % 4 == 0, "program GATHER: N=%d", j.N);
       return (j.M * j.N / 4 + 255) / 256;
+    case FL_PJOB_PSAMPLE:
+      FL_REQUIRE(j.A[0] && j.A[1] && j.W[0] && j.W[1] && j.W[2] && j.aux[2] && (j.A[2] || j.aux[0]) &&
+                     ((long long)j.M * j.N) % 4 == 0,
+                 "program PSAMPLE: needs x, eps, alpha/alpha_bar/beta tables, t and noise or a Philox offset (M*N %% 4 == 0)");
+      return (int)(((long long)j.M * j.N / 4 + 255) / 256);
     default:
       fl::set_error("program job: unknown kind %d", j.kind);
       return FL_ERR_BAD_ARG;
@@ -613,7 +685,7 @@ int fl_program_job_tiles(const void* job) {
 int fl_program_sync_bytes(void) { return SYNC_UINTS * 4; }
 
 int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_jobs, const void* const* io, int n_io,
-                   void* sync, int max_blocks, fl_stream_t stream) {
+                   void* sync, int max_blocks, const void* post, fl_stream_t stream) {
   FL_REQUIRE(phases && jobs && sync && n_phases >= 1 && n_jobs >= 1 && n_io >= 0 && n_io <= FL_PROG_MAX_IO && (n_io == 0 || io),
              "fl_program_run: bad args (n_phases=%d n_jobs=%d n_io=%d)", n_phases, n_jobs, n_io);
   FL_REQUIRE((size_t)n_phases * sizeof(fl_pphase) + (size_t)n_jobs * sizeof(fl_pjob) <= (size_t)PROG_LDS_BYTES,
@@ -621,6 +693,8 @@ int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_job
              PROG_LDS_BYTES);
   ProgIO pio;
   for (int i = 0; i < FL_PROG_MAX_IO; ++i) pio.p[i] = i < n_io ? io[i] : nullptr;
+  memset(&pio.post, 0, sizeof(pio.post));
+  if (post) pio.post = *reinterpret_cast<const fl_program_post*>(post);
   for (int i = 0; i < n_io; ++i)
     FL_REQUIRE((reinterpret_cast<uintptr_t>(io[i]) & 15) == 0, "fl_program_run: io[%d] is not 16-byte aligned", i);
   const int cus = device_cus();

@@ -13,14 +13,15 @@ import torch
 
 from . import lib, ops
 
-GEMM, ROWNORM, SINUSOID, GATHER = 0, 1, 2, 3
+GEMM, ROWNORM, SINUSOID, GATHER, PSAMPLE = 0, 1, 2, 3, 4
 MAX_IO = 16
 
 JOB_DTYPE = np.dtype([
     ("A", "<u8", 3), ("W", "<u8", 3), ("bias", "<u8", 3), ("R", "<u8"), ("C", "<u8"), ("mask", "<u8"), ("gate", "<u8"),
     ("aux", "<u8", 4), ("kind", "<i4"), ("M", "<i4"), ("N", "<i4"), ("nseg", "<i4"), ("K", "<i4", 3), ("lda", "<i4", 3),
     ("ldw", "<i4", 3), ("ldr", "<i4"), ("ldc", "<i4"), ("act", "<i4"), ("mask_group", "<i4"), ("tile_begin", "<i4"),
-    ("ntiles", "<i4"), ("bias_scale", "<f4", 3), ("eps", "<f4"), ("eps2", "<f4"), ("pad_", "<i4", 2)])
+    ("ntiles", "<i4"), ("bias_scale", "<f4", 3), ("eps", "<f4"), ("eps2", "<f4"), ("bias_row_stride", "<i4"), ("pad_", "<i4")])
+POST_DTYPE = np.dtype([("ptr64", "<u8", 2), ("delta64", "<i8", 2), ("ptr32", "<u8"), ("delta32", "<i4"), ("pad_", "<i4")])
 PHASE_DTYPE = np.dtype([("job_begin", "<i4"), ("job_end", "<i4"), ("ntiles", "<i4"), ("flags", "<i4")])
 PHASE_ACQUIRE = 1
 SYNC_ABORT_WORD = 8 * 1024 + 16
@@ -77,8 +78,10 @@ class ProgramBuilder:
         self._phases[-1].append((job, [self._key(r) for r in reads if r is not None],
                                  [self._key(w) for w in writes if w is not None]))
 
-    def gemm(self, M, N, segs, C, ldc, biases=(), act=ops.ACT_NONE, R=None, ldr=0, mask=None, mask_group=0, gate=None):
-        """C[M,N] = epi(sum_s A_s W_s^T). segs: [(A, lda, K, W, ldw)]; biases: [(bias, scale)]."""
+    def gemm(self, M, N, segs, C, ldc, biases=(), act=ops.ACT_NONE, R=None, ldr=0, mask=None, mask_group=0, gate=None,
+             bias_row_index=None, bias_row_stride=0):
+        """C[M,N] = epi(sum_s A_s W_s^T). segs: [(A, lda, K, W, ldw)]; biases: [(bias, scale)]; with bias_row_index (a
+        device int64) biases[0] is row *index of a table with row stride bias_row_stride."""
         j = np.zeros((), JOB_DTYPE)
         j["kind"], j["M"], j["N"], j["nseg"] = GEMM, M, N, len(segs)
         for s, (A, lda, K, W, ldw) in enumerate(segs):
@@ -90,8 +93,9 @@ class ProgramBuilder:
         j["C"], j["ldc"], j["act"] = _ptr(C), ldc, act
         j["R"], j["ldr"] = _ptr(R), ldr
         j["mask"], j["mask_group"], j["gate"] = _ptr(mask), mask_group, _ptr(gate)
-        self._hold(C, R, mask, gate)
-        self._add(j, [a[0] for a in segs] + [R, mask], [C])
+        j["aux"][2], j["bias_row_stride"] = _ptr(bias_row_index), bias_row_stride
+        self._hold(C, R, mask, gate, bias_row_index)
+        self._add(j, [a[0] for a in segs] + [R, mask, bias_row_index], [C])
 
     def rownorm(self, M, D, x, ldx, w, b, eps, C, ldc, act=ops.ACT_NONE, mask=None, R=None, ldr=0, w2=None, b2=None,
                 eps2=1e-5, C2=None, gate=None, gx=None, ldgx=0):
@@ -117,6 +121,17 @@ class ProgramBuilder:
         j["A"][0], j["lda"][0], j["W"][0], j["C"], j["ldc"] = _ptr(table), ld_table, _ptr(idx), _ptr(C), ldc
         self._hold(table, idx, C)
         self._add(j, [idx], [C])
+
+    def psample(self, M, N, x, eps, t64, alpha, alpha_bar, beta, noise=None, philox_offset=None, seed=0):
+        """x <- DDPM reverse update (in place); noise tensor or inline Philox (seed, device offset)."""
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = PSAMPLE, M, N
+        j["A"][0], j["A"][1], j["A"][2], j["C"], j["ldc"] = _ptr(x), _ptr(eps), _ptr(noise), _ptr(x), N
+        j["W"][0], j["W"][1], j["W"][2] = _ptr(alpha), _ptr(alpha_bar), _ptr(beta)
+        j["aux"][0], j["aux"][2] = _ptr(philox_offset), _ptr(t64)
+        j["K"][0], j["K"][1] = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32).view(np.int32)
+        self._hold(x, eps, t64, alpha, alpha_bar, beta, noise, philox_offset)
+        self._add(j, [x, eps, t64, noise, philox_offset], [x])
 
     def finalize(self, device):
         L = lib.load()
@@ -162,12 +177,26 @@ class Program:
         self.sync = torch.zeros(lib.load().fl_program_sync_bytes() // 4, dtype=torch.int32, device=device)
         self.max_blocks = 0  # 0 = one block per CU
 
-    def run(self, io):
-        """io: list of tensors bound to the IO slots. Enqueues one kernel on the current stream (graph-capturable)."""
+    def run(self, io, post=None):
+        """io: list of tensors bound to the IO slots. Enqueues one kernel on the current stream (graph-capturable).
+        post: [(int64 tensor, delta), ...] (at most 2) and/or an (int32 tensor, delta): counters bumped once per run,
+        after the last phase."""
         arr = (ctypes.c_void_p * MAX_IO)(*[t.data_ptr() for t in io])
+        pbuf = None
+        if post:
+            pp = np.zeros((), POST_DTYPE)
+            k = 0
+            for t, d in post:
+                if t.dtype == torch.int64:
+                    pp["ptr64"][k], pp["delta64"][k] = t.data_ptr(), d
+                    k += 1
+                else:
+                    assert t.dtype == torch.int32
+                    pp["ptr32"], pp["delta32"] = t.data_ptr(), d
+            pbuf = ctypes.c_char_p(pp.tobytes())
         lib.call("fl_program_run", ctypes.c_void_p(self.phases.data_ptr()), ctypes.c_void_p(self.jobs.data_ptr()),
                  self.n_phases, self.n_jobs, arr, len(io), ctypes.c_void_p(self.sync.data_ptr()), self.max_blocks,
-                 ops._stream())
+                 pbuf, ops._stream())
 
     def check(self):
         """Synchronising health check: raises if a barrier timed out (and re-arms the counters)."""
@@ -295,3 +324,99 @@ class UNetProgram:
                 io[BM0 + i], io[HM0 + i] = block_masks[i], head_masks[i]
         self.prog.run(io)
         return out
+
+
+# ------------------------------------------------------------------------------------------------ sampler step
+class SamplerProgram:
+    """One DDPM reverse step (v2:580-592) as ONE persistent launch of 16 phases: denoiser + update + Philox noise +
+    step counter. Everything that does not depend on x is hoisted out of the 1000-step loop ("class path
+    hoistable"), and with frozen eval-mode weights the linear chains are folded:
+      * per-timestep tables (n_steps rows): TE = time_emb(t); TPt_i = W_tp_i TE; FT = W_ft TE  -> one table row per
+        step is added as a bias picked by the device-resident step counter;
+      * per-sample constants: ce = class_emb(c); TPc_i = W_tp_i ce + biases; FC = W_fc ce + biases -> residual inputs;
+      * attention with one token is out_proj(v_proj(.)) and no nonlinearity follows before the next
+        layer's Linear, so  down(out_proj(v_proj(hn)) + h2) = (W_d W_o W_v) hn + W_d h2 + const  is ONE contraction
+        over [hn | h2] with pre-multiplied weights.
+    Per layer: h1 GEMM, Linear GEMM, (LN, Swish, +h1, LN) row phase = 3 phases instead of 5; 6.4 MMAC/sample -> 4.9."""
+
+    def __init__(self, diffusion, B, device, x, t64, t32, c=None, noise=None):
+        d_ = lambda p: p.detach()
+        un = diffusion.eps_model
+        self.d, self.B, self.x, self.t64, self.t32 = diffusion, B, x, t64, t32
+        f32 = dict(dtype=torch.float32, device=device)
+        E, T = un.time_emb_dim, diffusion.n_steps
+        SW = ops.ACT_SWISH
+        with torch.no_grad():
+            TE = un.time_emb(torch.arange(T, dtype=torch.int64, device=device))          # (T, E)
+            ce = un.class_emb(c) if c is not None else None                              # (B, E)
+            tb = 2.0 if c is not None else 1.0
+            pb = ProgramBuilder()
+            self.keep = [TE, ce]
+            prev_segs = [(x, un.latent_dim, un.latent_dim, d_(un.latent_proj.weight), un.latent_dim)]
+            const = d_(un.latent_proj.bias).clone()
+            for i, (block, norm, down) in enumerate(un.layers):
+                lin, ln = block[0], block[1]
+                D = lin.weight.shape[0]
+                tp, att = un.time_projections[i], un.attention_layers[i]
+                TPt = ops.linear(TE, d_(tp.weight))                                        # (T, D), no bias
+                const = const + tb * d_(tp.bias)
+                if ce is not None:
+                    extra = ops.linear(ce, d_(tp.weight), const.contiguous())             # (B, D): W_tp ce + consts
+                h1, g, h2, hn = (torch.empty(B, D, **f32) for _ in range(4))
+                self.keep += [TPt, h1, g, h2, hn]
+                if ce is not None:
+                    self.keep.append(extra)
+                    pb.gemm(B, D, prev_segs, h1, D, [(TPt, 1.0)], R=extra, ldr=D, bias_row_index=t64, bias_row_stride=D)
+                else:
+                    cst = const.contiguous()
+                    self.keep.append(cst)
+                    pb.gemm(B, D, prev_segs, h1, D, [(TPt, 1.0), (cst, 1.0)], bias_row_index=t64, bias_row_stride=D)
+                pb.barrier()
+                pb.gemm(B, D, [(h1, D, D, d_(lin.weight), D)], g, D, [(d_(lin.bias), 1.0)])
+                pb.barrier()
+                pb.rownorm(B, D, g, D, d_(ln.weight), d_(ln.bias), ln.eps, h2, D, act=SW, R=h1, ldr=D, w2=d_(norm.weight),
+                           b2=d_(norm.bias), eps2=norm.eps, C2=hn)
+                pb.barrier()
+                # fold: next input = W_d (W_o (W_v hn + b_v) + b_o + h2) + b_d
+                Wv, bv = d_(att.in_proj_weight)[2 * D:], d_(att.in_proj_bias)[2 * D:]
+                Wo, bo = d_(att.out_proj.weight), d_(att.out_proj.bias)
+                Wd, bd = d_(down.weight), d_(down.bias)
+                Dn = Wd.shape[0]
+                Wov = ops.gemm(Wo, Wv, D, D, D, b_layout=ops.KS, ldb=D)                    # W_o W_v
+                bov = ops.linear(bv.reshape(1, D).contiguous(), Wo, bo)                    # W_o b_v + b_o  (1, D)
+                Wcat = torch.empty(Dn, 2 * D, **f32)
+                Wcat[:, :D] = ops.gemm(Wd, Wov, Dn, D, D, b_layout=ops.KS, ldb=D)          # W_d W_o W_v
+                Wcat[:, D:] = Wd
+                const = ops.linear(bov, Wd, bd).reshape(Dn)                                # W_d b_ov + b_d
+                self.keep.append(Wcat)
+                prev_segs = [(hn, D, D, Wcat, 2 * D), (h2, D, D, (Wcat, D), 2 * D)]
+            ft, fcp, fn, fin = un.final_time_proj, un.final_class_proj, un.final_norm, un.final
+            Dl = ft.weight.shape[0]
+            FT = ops.linear(TE, d_(ft.weight))                                            # (T, Dl)
+            const = const + d_(ft.bias)
+            hpre, u, eps = torch.empty(B, Dl, **f32), torch.empty(B, Dl, **f32), torch.empty(B, un.latent_dim, **f32)
+            self.keep += [FT, hpre, u, eps]
+            if ce is not None:
+                extra = ops.linear(ce, d_(fcp.weight), (const + d_(fcp.bias)).contiguous())
+                self.keep.append(extra)
+                pb.gemm(B, Dl, prev_segs, hpre, Dl, [(FT, 1.0)], R=extra, ldr=Dl, bias_row_index=t64, bias_row_stride=Dl)
+            else:
+                cst = const.contiguous()
+                self.keep.append(cst)
+                pb.gemm(B, Dl, prev_segs, hpre, Dl, [(FT, 1.0), (cst, 1.0)], bias_row_index=t64, bias_row_stride=Dl)
+            pb.barrier()
+            rw = d_(un.residual_weight)
+            pb.rownorm(B, Dl, hpre, Dl, d_(fn.weight), d_(fn.bias), fn.eps, u, Dl, gate=rw, gx=x, ldgx=un.latent_dim)
+            pb.barrier()
+            pb.gemm(B, un.latent_dim, [(u, Dl, Dl, d_(fin.weight), Dl)], eps, un.latent_dim, [(d_(fin.bias), 1.0)], gate=rw)
+            pb.barrier()
+            st = diffusion.rng.state(device)
+            self.n4 = (B * un.latent_dim + 3) // 4
+            pb.psample(B, un.latent_dim, x, eps, t64, diffusion.alpha, diffusion.alpha_bar, diffusion.beta, noise=noise,
+                       philox_offset=None if noise is not None else st, seed=diffusion.rng.seed)
+            self.post = [(t64, -1), (t32, -1)] + ([] if noise is not None else [(st, self.n4)])
+            self.eps = eps
+            self.prog = pb.finalize(device)
+
+    def step(self):
+        self.prog.run([], post=self.post)

@@ -4,22 +4,38 @@ The reference's loop makes a tensor->bool host sync every step (`if t[0] > 0`, v
 eager kernels per step. Here one reverse step = denoiser forward + Philox noise + fused update + device-side
 step counter is captured once and replayed; `t` lives in device memory (int32 for the update kernel, int64 for
 the time embedding), so there is no host round trip inside the 1000-step loop."""
+import os
+
 import torch
 
 from . import engine, ops
 
+PERSISTENT = os.environ.get("FL_PERSISTENT", "1") != "0"
+
 
 class GraphSampler:
-    def __init__(self, diffusion, shape, device, c=None, use_graph=True):
+    """persistent=True (default): one reverse step is ONE launch of the persistent phase program (program.SamplerProgram:
+    denoiser with the x-independent paths hoisted and the eval-mode linear chains folded, the update, inline Philox
+    noise and the step counters); False: the multi-kernel engine forward + three small kernels per step."""
+
+    def __init__(self, diffusion, shape, device, c=None, use_graph=True, persistent=None):
         self.d = diffusion
         self.shape = tuple(shape)
         self.device = torch.device(device)
         self.c = c.long().contiguous() if c is not None else None
         self.use_graph = use_graph
         self.graph = None
+        self.persistent = PERSISTENT if persistent is None else persistent
+        self.sprog = None
 
     def _step(self):
         d = self.d
+        if self.persistent:
+            if self.sprog is None:
+                from .program import SamplerProgram
+                self.sprog = SamplerProgram(d, self.shape[0], self.device, self.x, self.t64, self.t32, c=self.c)
+            self.sprog.step()
+            return
         eps, _ = engine.unet_forward(d.eps_model, self.x, self.t64, self.c, None, None, save=False)
         d.rng.normal(self.shape, self.device, out=self.noise)
         ops.p_sample_update(self.x, eps, self.noise, self.t32, d.alpha, d.alpha_bar, d.beta, out=self.x)
@@ -52,6 +68,8 @@ class GraphSampler:
         else:
             for _ in range(n_steps - done):
                 self._step()
+        if self.sprog is not None:
+            self.sprog.prog.check()  # a barrier time-out voids the run (raises)
         if was_training:
             d.eps_model.train()
         return self.x

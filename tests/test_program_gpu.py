@@ -179,3 +179,49 @@ def test_unet_program_ce_given(dev):
         ce = un.class_emb(c)
         out = P.UNetProgram(un, B, dev, shared_t=True, has_class=True, ce_given=True)(x, t, ce=ce)
     close(out, ref, 3e-5, "ce_given")
+
+
+def test_sampler_program_vs_golden_trajectory(dev):
+    """20 reverse steps of the reference (tests/golden/unet.npz: traj / traj_noise / traj_c, generated by the
+    reference's own p_sample) replayed with the folded one-launch step and the reference's noise. Tolerance 2e-4 as
+    for the multi-kernel p_sample test (20 dependent steps)."""
+    import json
+    import os
+    import numpy as np
+    from oracle import procedural_init as pinit
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    f = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, "unet.npz")).items()}
+    sd = pinit.procedural_state_dict(json.load(open(os.path.join(G, "state_dict_shapes.json")))["unet"], 44)
+    un = M.ConditionalUNet().to(dev).eval()
+    un.load_state_dict(sd)
+    d = M.ConditionalDenoiseDiffusion(un, n_steps=1000, device=dev)
+    x = f["traj"][0].to(dev).clone()
+    B = x.shape[0]
+    n = f["traj_noise"].shape[0]
+    t64 = torch.tensor([n - 1], dtype=torch.int64, device=dev)
+    t32 = torch.tensor([n - 1], dtype=torch.int32, device=dev)
+    noise = torch.empty(B, 256, device=dev)
+    sp = P.SamplerProgram(d, B, dev, x, t64, t32, c=f["traj_c"].to(dev), noise=noise)
+    assert sp.prog.n_phases == 16
+    for i in range(n):
+        noise.copy_(f["traj_noise"][i])
+        sp.step()
+        close(x, f["traj"][i + 1], 2e-4, "folded p_sample step %d" % i)
+    sp.prog.check()
+    assert int(t64) == -1 and int(t32) == -1
+
+
+def test_sampler_persistent_equals_multikernel(dev):
+    """Same Philox stream, same x_T: the one-launch sampler and the multi-kernel sampler agree (fp32 re-association of
+    the folded weights only), with and without class conditioning."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd.sampler import GraphSampler
+    un = _unet(dev, 1).eval()
+    d = M.ConditionalDenoiseDiffusion(un, n_steps=1000, device=dev)
+    B = 40
+    x_T = rnd(B, 256, seed=3)
+    for c in (None, (torch.arange(B) % 102).to(dev)):
+        d.rng.manual_seed(11)
+        a = GraphSampler(d, (B, 256), dev, c, use_graph=True, persistent=True).run(x_T, n_steps=15, t_start=14).clone()
+        d.rng.manual_seed(11)
+        b = GraphSampler(d, (B, 256), dev, c, use_graph=True, persistent=False).run(x_T, n_steps=15, t_start=14).clone()
+        close(a, b, 1e-4, "persistent vs multi-kernel sampler")
