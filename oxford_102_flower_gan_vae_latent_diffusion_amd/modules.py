@@ -8,6 +8,7 @@ backward run hand-written HIP kernels through engine.py / ops.py. Module I/O is 
 reference; internally activations are NHWC.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -390,6 +391,9 @@ class ClassEmbedding(nn.Module):
         return ops.linear(h, self.lin2.weight.detach(), self.lin2.bias.detach())
 
 
+PERSISTENT_FORWARD = os.environ.get("FL_PERSISTENT", "1") != "0"
+
+
 class ConditionalUNet(nn.Module):
     """v2:501-561 — the live denoiser: an MLP over flat latents with length-1 'attention'."""
 
@@ -449,8 +453,26 @@ class ConditionalUNet(nn.Module):
             names = [n for n, _ in self.named_parameters()]
             params = [p for _, p in self.named_parameters()]
             return _UNetFn.apply(self, names, x, t, c, block_masks, head_masks, *params)
+        if PERSISTENT_FORWARD and x.shape[0] > 0:
+            return self._persistent_forward(x, t, c, block_masks, head_masks)
         out, _ = engine.unet_forward(self, x, t, c, block_masks, head_masks, save=False)
         return out
+
+    def _persistent_forward(self, x, t, c, block_masks, head_masks):
+        """Inference forward as ONE launch of the persistent phase program (program.UNetProgram), cached per call
+        signature; rebuilt when a parameter tensor is re-allocated. FL_PERSISTENT=0 selects the multi-kernel engine."""
+        from .program import UNetProgram
+        B = x.shape[0]
+        shared_t = t.numel() == 1 and B != 1
+        key = (B, shared_t, c is not None, block_masks is not None, x.device)
+        cache = self.__dict__.setdefault("_programs", {})
+        up = cache.get(key)
+        if up is None or up.key != UNetProgram.weights_key(self):
+            if len(cache) >= 8:
+                cache.clear()
+            up = UNetProgram(self, B, x.device, shared_t=shared_t, has_class=c is not None, masks=block_masks is not None)
+            cache[key] = up
+        return up(x, t.contiguous(), c.contiguous() if c is not None else None, block_masks, head_masks)
 
 
 class _UNetFn(torch.autograd.Function):

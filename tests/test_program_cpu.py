@@ -1,0 +1,86 @@
+"""Host side of the persistent phase-program executor (no GPU): struct packing against the library, job shape rules,
+tile counts, the stale-cache (acquire) analysis of the builder, and the io-slot encoding."""
+import numpy as np
+import pytest
+import torch
+
+from oxford_102_flower_gan_vae_latent_diffusion_amd import lib, program as P
+
+
+def phases_of(prog):
+    return np.frombuffer(prog.phases.numpy().tobytes(), dtype=P.PHASE_DTYPE)
+
+
+def jobs_of(prog):
+    return np.frombuffer(prog.jobs.numpy().tobytes(), dtype=P.JOB_DTYPE)
+
+
+def test_struct_packing_matches_library():
+    L = lib.load()
+    assert P.JOB_DTYPE.itemsize == L.fl_program_job_bytes() == 240
+    assert P.PHASE_DTYPE.itemsize == L.fl_program_phase_bytes() == 16
+    assert L.fl_program_sync_bytes() >= 4 * (P.SYNC_ABORT_WORD + 1)
+    assert P.POST_DTYPE.itemsize == 48
+
+
+def test_tile_counts_and_phase_layout():
+    pb = P.ProgramBuilder()
+    a, w, c = torch.zeros(100, 64), torch.zeros(96, 64), torch.zeros(100, 96)
+    x, g, b = torch.zeros(70, 512), torch.zeros(512), torch.zeros(512)
+    pb.gemm(100, 96, [(a, 64, 64, w, 64)], c, 96)                      # ceil(100/32) * 96/32 = 12 tiles
+    pb.rownorm(70, 512, x, 512, g, b, 1e-5, torch.zeros(70, 512), 512)  # ceil(70/4) = 18 tiles
+    pb.barrier()
+    pb.sinusoid(3, 256, torch.zeros(3, dtype=torch.int64), 1, torch.zeros(128), torch.zeros(3, 256), 256)  # 384/256 -> 2
+    pb.gather(5, 256, torch.zeros(10, 256), 256, torch.zeros(5, dtype=torch.int64), torch.zeros(5, 256), 256)  # 320/256 -> 2
+    prog = pb.finalize("cpu")
+    ph, jb = phases_of(prog), jobs_of(prog)
+    assert [tuple(p)[:3] for p in ph] == [(0, 2, 30), (2, 4, 4)]
+    assert list(jb["ntiles"]) == [12, 18, 2, 2] and list(jb["tile_begin"]) == [0, 12, 0, 2]
+    assert prog.max_tiles == 30 and prog.n_jobs == 4
+
+
+@pytest.mark.parametrize("bad", ["K", "lda", "N", "rownorm_D", "rownorm_second", "psample"])
+def test_shape_rules_are_enforced(bad):
+    pb = P.ProgramBuilder()
+    z = torch.zeros
+    if bad == "K":
+        pb.gemm(8, 32, [(z(8, 42), 44, 42, z(32, 44), 44)], z(8, 32), 32)
+    elif bad == "lda":
+        pb.gemm(8, 32, [(z(8, 42), 42, 40, z(32, 40), 40)], z(8, 32), 32)
+    elif bad == "N":
+        pb.gemm(8, 40, [(z(8, 64), 64, 64, z(40, 64), 64)], z(8, 40), 40)
+    elif bad == "rownorm_D":
+        pb.rownorm(8, 320, z(8, 320), 320, z(320), z(320), 1e-5, z(8, 320), 320)
+    elif bad == "rownorm_second":
+        pb.rownorm(8, 256, z(8, 256), 256, z(256), z(256), 1e-5, z(8, 256), 256, w2=z(256))
+    else:
+        pb.psample(3, 6, z(3, 6), z(3, 6), z(1, dtype=torch.int64), z(10), z(10), z(10), philox_offset=z(1, dtype=torch.int64))
+    with pytest.raises(ValueError):
+        pb.finalize("cpu")
+
+
+def test_acquire_only_where_a_cached_buffer_was_overwritten():
+    a, b, c, w = torch.zeros(64, 64), torch.zeros(64, 64), torch.zeros(64, 64), torch.zeros(64, 64)
+    pb = P.ProgramBuilder()
+    pb.gemm(64, 64, [(a, 64, 64, w, 64)], b, 64)   # reads a
+    pb.barrier()
+    pb.gemm(64, 64, [(b, 64, 64, w, 64)], c, 64)   # reads b (fresh), writes c
+    pb.barrier()
+    pb.gemm(64, 64, [(c, 64, 64, w, 64)], a, 64)   # overwrites a, which phase 0 may have cached
+    pb.barrier()
+    pb.gemm(64, 64, [(b, 64, 64, w, 64)], c, 64)   # b is still valid: no acquire; overwrites c (cached by phase 2)
+    pb.barrier()
+    pb.gemm(64, 64, [(a, 64, 64, w, 64)], b, 64)   # re-reads a after the overwrite -> acquire
+    pb.barrier()
+    pb.gemm(64, 64, [(c, 64, 64, w, 64)], a, 64)   # the acquire dropped every cached line: c is read fresh -> none
+    assert list(phases_of(pb.finalize("cpu"))["flags"]) == [0, 0, 0, 0, P.PHASE_ACQUIRE, 0]
+
+
+def test_io_slots_are_encoded_as_small_integers():
+    pb = P.ProgramBuilder()
+    w = torch.zeros(32, 32)
+    pb.gemm(4, 32, [(P.IO(0), 32, 32, w, 32)], P.IO(3), 32, R=P.IO(15), ldr=32)
+    jb = jobs_of(pb.finalize("cpu"))[0]
+    assert jb["A"][0] == 1 and jb["C"] == 4 and jb["R"] == 16 and jb["W"][0] == w.data_ptr()
+    with pytest.raises(AssertionError):
+        P.IO(16)
