@@ -79,4 +79,11 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// conv_first.hip: dedicated nn.Conv2d(3->64, 3x3, pad 1) kernel (input NHWC padded to 4 channels), used by the
+// fl_conv2d_fwd / fl_conv2d_fwd_instnorm entry points of gemm.hip when the shape matches
+bool conv3x3_c4_o64_applicable(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int act);
+int conv3x3_c4_o64_slabs(int H, int W);
+int launch_conv3x3_c4_o64(const float* x, const float* wp, const float* bias, float* y, float* partial, int B, int H, int W,
+                          int act, float act_param, hipStream_t s);
+
 }  // namespace fl

@@ -355,3 +355,26 @@ def test_losses_and_optimizer(dev):
         ops.adam_step(pd, gd, md, vd, lr_dev, step_dev, wd=1e-5, coef_dev=coef)
         close(nrm, tn.reshape(1), tol=1e-5)
         close(pd, pr.data, tol=2e-6)
+
+
+@pytest.mark.parametrize("B,HW,act", [(1, 64, 0), (3, 64, 2), (2, 32, 1)])
+def test_conv_stem_dedicated_kernel(dev, B, HW, act):
+    """nn.Conv2d(3, 64, 3, padding=1) (v2:186; VGG16 features[0]): routed to the dedicated K=36 kernel (conv_first.hip),
+    with and without the fused LayerNorm2d statistics; reference = F.conv2d in fp64 on CPU."""
+    x = rnd(B, 3, HW, HW, seed=1)
+    w = rnd(64, 3, 3, 3, seed=2, scale=0.3)
+    bias = rnd(64, seed=3)
+    lw, lb = rnd(64, seed=4), rnd(64, seed=5)
+    xh = ops.nchw_to_nhwc(x.to(dev), 4)
+    wp = ops.pack_conv_weight(w.to(dev), Ipad=4)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    y = ops.conv2d_fwd(xh, wp, bias.to(dev), 1, 1, act=act, act_param=0.2)
+    close(nchw(y), act_ref(ref, act), tol=1e-5)
+    y2, (sc, sh, mean, rstd) = ops.conv2d_fwd_instnorm(xh, wp, bias.to(dev), 1, 1, lw.to(dev), lb.to(dev), 1e-5)
+    close(nchw(y2), ref, tol=1e-5)
+    m = ref.mean((2, 3))
+    v = ref.var((2, 3), unbiased=False)
+    close(mean, m, tol=1e-5)
+    close(rstd, 1 / torch.sqrt(v + 1e-5), tol=2e-5)
+    close(sc, lw.double() / torch.sqrt(v + 1e-5), tol=2e-5)
+    close(sh, lb.double() - m * lw.double() / torch.sqrt(v + 1e-5), tol=3e-5)
