@@ -56,14 +56,16 @@ def resblock_infer(x, rb, pk):
                                                    _d(rb.ln2.bias), rb.ln2.eps)
     # avg_pool(LayerNorm2d(y)) == ln2.bias exactly (normalised maps have zero spatial mean), so the
     # channel-attention gate (v2:65-66) is one (C,) vector shared by the batch: no pooling pass.
-    s = ca_gate(rb.ca, _d(rb.ln2.bias).view(1, -1)).view(-1)
+    # ... and a function of the weights only: computed once per weight version, not per batch.
+    s = pk.get(("cagate", id(rb)), [rb.ca.conv_du[0].weight, rb.ca.conv_du[2].weight, rb.ln2.bias],
+               lambda: ca_gate(rb.ca, _d(rb.ln2.bias).view(1, -1)).view(-1))
     m = ops.res_tail_map(y2, sc2, sh2, s)
     return ops.res_tail_out(y2, sc2, sh2, s, m, _d(rb.sa.conv.weight).contiguous(), xres=x, final_swish=True)
 
 
-def _head(fc, flat):
-    """Linear -> LayerNorm -> Swish -> Linear (v2:210-221)."""
-    g = ops.linear(flat, _d(fc[0].weight), _d(fc[0].bias))
+def _head(fc, flat, w0=None):
+    """Linear -> LayerNorm -> Swish -> Linear (v2:210-221). w0: fc[0].weight re-laid out for an NHWC-flattened input."""
+    g = ops.linear(flat, w0 if w0 is not None else _d(fc[0].weight), _d(fc[0].bias))
     g, _, _ = ops.layernorm_fwd(g, _d(fc[1].weight), _d(fc[1].bias), eps=fc[1].eps, act=SW, save=False)
     return ops.linear(g, _d(fc[3].weight), _d(fc[3].bias))
 
@@ -84,8 +86,16 @@ def encoder_infer(enc, x):
         h = ops.affine_act(y, sc, sh, act=SW, out=y)
         h = resblock_infer(h, rb, pk)
         feats.append(h)
-    flat = ops.nhwc_to_nchw(h).view(B, -1)  # x.view(B,-1) of the NCHW tensor (v2:236)
-    return _head(enc.fc_mu, flat), _head(enc.fc_logvar, flat), feats
+    # x.view(B,-1) of the NCHW tensor (v2:236): instead of transposing 33 MB of activations per batch, the columns of the
+    # two 512 x 32768 head weights are permuted to NHWC order once per weight version
+    Hh, Wh, Ch = h.shape[1], h.shape[2], h.shape[3]
+    flat = h.view(B, -1)
+
+    def perm(fc):
+        w = fc[0].weight
+        return pk.get(("fc_nhwc", id(fc)), [w], lambda: ops.nchw_to_nhwc(w.detach().view(-1, Ch, Hh, Wh)).view(w.shape[0], -1))
+
+    return _head(enc.fc_mu, flat, perm(enc.fc_mu)), _head(enc.fc_logvar, flat, perm(enc.fc_logvar)), feats
 
 
 def decoder_infer(dec, z):

@@ -23,6 +23,8 @@ def timeit(fn, n=30):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 print("encoder graph: %.3f ms" % timeit(g.replay))
+if os.environ.get("ENC_ONLY"):
+    sys.exit(0)
 z0 = z.clone()
 g2 = torch.cuda.CUDAGraph()
 tr.fwd_bwd(z0, labels); tr.update(); torch.cuda.synchronize()
