@@ -169,6 +169,11 @@ int fl_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, int Cpad, fl
 int fl_act_fwd(const float* x, float* y, int64_t n, int act, float p, fl_stream_t stream);          /* Swish v2:48-50 */
 int fl_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, float p, fl_stream_t stream);
 int fl_axpby(float a, const float* x, float b, const float* y, float* out, int64_t n, fl_stream_t stream);
+/* dst[i][:] = a*src[i][:] + b*dst[i][:] for `entries` independent (src, dst, n) triples in as few launches as the
+ * kernel-argument table allows (96 per launch): per-parameter gradients -> flat gradient buffer (v2:1127, v2:1262).
+ * src/dst/n are HOST arrays. */
+int fl_multi_axpby(const void* const* src, void* const* dst, const int64_t* n, int entries, float a, float b,
+                   fl_stream_t stream);
 /* attention-dropout of nn.MultiheadAttention on a length-1 sequence (v2:514,550-551) */
 int fl_scale_heads(const float* v, const float* head_mask, float* out, int B, int D, int heads, fl_stream_t stream);
 int fl_add_rows(const float* x, const float* y, int y_rows, float* out, int B, int D, fl_stream_t stream);

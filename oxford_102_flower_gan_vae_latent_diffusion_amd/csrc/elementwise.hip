@@ -1,6 +1,8 @@
 // Elementwise / gather / diffusion-update / RNG kernels (all HBM- or latency-bound).
 #include "fl_common.h"
 
+#define FL_MULTI_MAX 96
+
 namespace {
 
 __device__ __forceinline__ float act_grad(float u, int act, float p) {
@@ -56,6 +58,30 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 __global__ void axpby_kernel(float a, const float* __restrict__ x, float b, const float* __restrict__ y,
                              float* __restrict__ out, long long n) {
   GRID_STRIDE(i, n) out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+// Many small copies / accumulations in ONE launch (per-parameter gradients into the flat gradient buffer: the VAE-GAN
+// step did 196 of them, 4.9 us each = launch floor). The table travels in the kernel arguments.
+struct MultiAxpby {
+  const float* src[FL_MULTI_MAX];
+  float* dst[FL_MULTI_MAX];
+  int blk0[FL_MULTI_MAX + 1];  // first block of each entry (1024 elements per block)
+  long long n[FL_MULTI_MAX];
+};
+__global__ void multi_axpby_kernel(const MultiAxpby t, int entries, float a, float b) {
+  int lo = 0, hi = entries - 1;  // last entry whose first block <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long base = (long long)(blockIdx.x - t.blk0[lo]) * 1024;
+  const float* __restrict__ x = t.src[lo];
+  float* __restrict__ y = t.dst[lo];
+  const long long n = t.n[lo];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + k * 256 + threadIdx.x;
+    if (i < n) y[i] = b != 0.f ? a * x[i] + b * y[i] : a * x[i];
+  }
 }
 // out[b, c] = v[b, c] * hm[b, c / (D/heads)]   (attention-dropout on a length-1 sequence, v2:514)
 __global__ void scale_heads_kernel(const float* __restrict__ v, const float* __restrict__ hm, float* __restrict__ out,
@@ -319,6 +345,27 @@ int fl_axpby(float a, const float* x, float b, const float* y, float* out, int64
   if (!n) return FL_OK;
   hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), a, x, b, y, out, (long long)n);
   return fl::check_launch("axpby");
+}
+int fl_multi_axpby(const void* const* src, void* const* dst, const int64_t* n, int entries, float a, float b,
+                   fl_stream_t stream) {
+  FL_REQUIRE(entries >= 0 && (entries == 0 || (src && dst && n)), "fl_multi_axpby: bad args");
+  for (int e0 = 0; e0 < entries; e0 += FL_MULTI_MAX) {
+    MultiAxpby t;
+    const int cnt = entries - e0 < FL_MULTI_MAX ? entries - e0 : FL_MULTI_MAX;
+    int blocks = 0;
+    for (int i = 0; i < cnt; ++i) {
+      FL_REQUIRE(src[e0 + i] && dst[e0 + i] && n[e0 + i] >= 0, "fl_multi_axpby: null entry %d", e0 + i);
+      t.src[i] = reinterpret_cast<const float*>(src[e0 + i]);
+      t.dst[i] = reinterpret_cast<float*>(dst[e0 + i]);
+      t.n[i] = n[e0 + i];
+      t.blk0[i] = blocks;
+      blocks += (int)((n[e0 + i] + 1023) / 1024);
+    }
+    t.blk0[cnt] = blocks;
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(multi_axpby_kernel, dim3(blocks), dim3(256), 0, ST(stream), t, cnt, a, b);
+  }
+  return fl::check_launch("multi_axpby");
 }
 int fl_scale_heads(const float* v, const float* head_mask, float* out, int B, int D, int heads, fl_stream_t stream) {
   FL_REQUIRE(heads > 0 && D % heads == 0, "fl_scale_heads: bad heads");

@@ -403,6 +403,22 @@ def axpby(a, x, b=0.0, y=None, out=None):
     return out
 
 
+def multi_axpby(pairs, a=1.0, b=0.0):
+    """dst = a*src + b*dst for every (src, dst) pair, batched into as few launches as possible."""
+    pairs = [(s_, d_) for s_, d_ in pairs if s_ is not None and s_.numel() > 0]
+    if not pairs:
+        return
+    k = len(pairs)
+    for s_, d_ in pairs:
+        _chk(s_, d_)
+        if s_.numel() != d_.numel():
+            raise ValueError("multi_axpby: size mismatch %s vs %s" % (tuple(s_.shape), tuple(d_.shape)))
+    src = (ctypes.c_void_p * k)(*[s_.data_ptr() for s_, _ in pairs])
+    dst = (ctypes.c_void_p * k)(*[d_.data_ptr() for _, d_ in pairs])
+    n = (ctypes.c_int64 * k)(*[s_.numel() for s_, _ in pairs])
+    _lib.call("fl_multi_axpby", src, dst, n, k, float(a), float(b), _stream())
+
+
 def scale_heads(v, head_mask, heads, out=None):
     _chk(v, head_mask, out)
     B, D = v.shape

@@ -62,15 +62,10 @@ class FlatParams:
 
     def set_grads(self, G, prefix=""):
         """copy a {name: grad} dict into the flat gradient buffer."""
-        for n, g in G.items():
-            if g is not None:
-                ops.axpby(1.0, g.contiguous(), out=self.gviews[prefix + n])
+        ops.multi_axpby([(g.contiguous(), self.gviews[prefix + n]) for n, g in G.items() if g is not None])
 
     def add_grads(self, G, prefix=""):
-        for n, g in G.items():
-            if g is not None:
-                v = self.gviews[prefix + n]
-                ops.axpby(1.0, g.contiguous(), 1.0, v, out=v)
+        ops.multi_axpby([(g.contiguous(), self.gviews[prefix + n]) for n, g in G.items() if g is not None], 1.0, 1.0)
 
     def bump(self):
         """Parameters were updated through raw pointers: invalidate derived (packed) layouts."""

@@ -378,3 +378,19 @@ def test_conv_stem_dedicated_kernel(dev, B, HW, act):
     close(rstd, 1 / torch.sqrt(v + 1e-5), tol=2e-5)
     close(sc, lw.double() / torch.sqrt(v + 1e-5), tol=2e-5)
     close(sh, lb.double() - m * lw.double() / torch.sqrt(v + 1e-5), tol=3e-5)
+
+
+def test_multi_axpby(dev):
+    """batched per-parameter gradient gather: > 96 entries (two launches), ragged sizes, both assign and accumulate."""
+    g = torch.Generator().manual_seed(0)
+    sizes = [int(torch.randint(1, 5000, (1,), generator=g)) for _ in range(130)] + [1, 1023, 1024, 1025, 70000]
+    src = [torch.randn(n, generator=g) for n in sizes]
+    dst0 = [torch.randn(n, generator=g) for n in sizes]
+    ds, dd = [s.to(dev) for s in src], [d.to(dev) for d in dst0]
+    ops.multi_axpby(list(zip(ds, dd)))
+    for s, d in zip(src, dd):
+        assert torch.equal(d.cpu(), s)
+    dd = [d.to(dev) for d in dst0]
+    ops.multi_axpby(list(zip(ds, dd)), 0.5, 2.0)
+    for s, d0, d in zip(src, dst0, dd):
+        close(d, 0.5 * s.double() + 2.0 * d0.double(), tol=1e-6)
