@@ -17,6 +17,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+SPLIT_PIECE_PRODUCTS = 6        # bf16 MFMAs issued per fp32 product in the default "split" GEMM math (flowers_hip.h)
 # algorithmic GFLOP per image (forward MACs x2): frozen encoder fwd + denoiser fwd+bwd (3x fwd)
 GFLOP_PER_IMAGE_STEP = 2.748
 
@@ -102,6 +104,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="do not pipeline encoder(k+1) under the denoiser update(k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-math", choices=("split", "fp32"), default=None,
+                    help="split (default): fp32 operands split exactly into 3 bf16 pieces, 6 piece products on the bf16 "
+                         "matrix pipe; fp32: native v_mfma_f32_32x32x2_f32")
     a = ap.parse_args()
     if os.environ.get("BENCH_WATCHDOG"):  # debugging aid: dump the python stack if a phase stalls
         import faulthandler
@@ -132,6 +137,14 @@ def main():
 
     from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M
     from oxford_102_flower_gan_vae_latent_diffusion_amd import ops, steps
+
+    if a.gemm_math is not None:
+        ops.set_gemm_math(a.gemm_math)
+    gemm_math = ops.get_gemm_math()
+    gemm_math_note = ("split: fp32 operands split exactly into 3 bf16 pieces (x = h+m+l), 6 of 9 piece products on "
+                      "v_mfma_f32_32x32x16_bf16, fp32 accumulation; dropped terms < 2^-21 per product "
+                      "(tests/test_kernels_gpu.py::test_split_mfma_is_fp32_equivalent); --gemm-math fp32 = native fp32 MFMA"
+                      if gemm_math == "split" else "fp32: native v_mfma_f32_32x32x2_f32")
 
     torch.manual_seed(1234)  # identical initial weights on every rank (random init of the v2 architecture)
     ae = M.SimpleAutoencoder().to(dev).eval()
@@ -224,19 +237,29 @@ def main():
             "hipgraph": use_graph,
             "encoder_denoiser_overlap": overlap,
             "loss": final_loss,
+            "gemm_math": gemm_math_note,
         },
     }
     if rank == 0 and world == 1:
         if not a.no_roofline:
             r = measure_dominant_kernel(dev, B)
             log("dominant kernel: %.1f TFLOP/s avg over %d launches" % (r["tflops"], r["launches"]))
+            split = gemm_math == "split"
+            # the fraction is taken against the peak of the instruction the kernel actually issues: in split mode one
+            # algorithmic fp32 flop costs SPLIT_PIECE_PRODUCTS bf16 flops, so the ceiling of the scheme is 2500/6 TFLOP/s
+            peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PIECE_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": "gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+                "kernel": "gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> (implicit-GEMM conv, " +
+                          ("6 x v_mfma_f32_32x32x16_bf16 per 16 k on exact bf16 pieces of the fp32 operands)" if split
+                           else "v_mfma_f32_32x32x2_f32)"),
                 "achieved": r["tflops"],
-                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": r["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                "frac": r["tflops"] / peak,
+                "peak_basis": ("bf16 dense MFMA peak %.0f / %d piece products per fp32 product" % (BF16_MFMA_PEAK_TFLOPS, SPLIT_PIECE_PRODUCTS))
+                              if split else "fp32 dense MFMA peak",
+                "achieved_over_fp32_mfma_peak": r["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                 # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, averaged over the 9
                 # launches at B=256; profiles/r01_conv_kernel_pmc.md). Not re-measured live: PMC needs the profiler.
                 "traffic": 4.08e8 if B == 256 else None,
@@ -244,7 +267,7 @@ def main():
                 "avg_launch_ms": r["avg_ms"],
                 "algorithmic_gflop_per_launch": r["flop_per_launch"] / 1e9,
                 "launches_per_step": r["launches"],
-                "step_frac_of_mfma_roofline": (GFLOP_PER_IMAGE_STEP * B * a.steps / dt / 1e3) / FP32_MFMA_PEAK_TFLOPS,
+                "step_frac_of_mfma_roofline": (GFLOP_PER_IMAGE_STEP * B * a.steps / dt / 1e3) / peak,
             }
         if not a.no_cpu_baseline:
             # one GPU's share of the host (the affinity mask of a shared 8-GPU host is much wider than this process should use)

@@ -60,6 +60,14 @@ const char* fl_last_error_string(void);
  * Split-K is used automatically when the tile count is small and `ws` allows.
  * ------------------------------------------------------------------------ */
 size_t fl_gemm_workspace_bytes(int M, int N, int K);
+/* How the GEMM core multiplies fp32 operands (all GEMM / conv entry points; set before capturing graphs):
+ *   0  v_mfma_f32_32x32x2_f32 on the fp32 matrix path (157 TFLOP/s peak);
+ *   1  (default; env FL_GEMM_MATH=fp32 selects 0) every operand is split EXACTLY into three bf16 pieces
+ *      x = h + m + l and the product is assembled from 6 of the 9 piece products on v_mfma_f32_32x32x16_bf16
+ *      (piece products exact, fp32 accumulation); dropped terms m*l, l*m, l*l < 2^-21 |x*y| per product, below the
+ *      rounding noise of an fp32 accumulation over K >= 64 terms. Unaligned operands always take mode 0. */
+int fl_set_gemm_math(int mode);
+int fl_get_gemm_math(void);
 int fl_gemm_f32(const float* A, int64_t lda, int a_layout,
                 const float* B, int64_t ldb, int b_layout,
                 float* C, int64_t ldc, int M, int N, int K,

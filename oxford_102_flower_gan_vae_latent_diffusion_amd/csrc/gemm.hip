@@ -30,11 +30,45 @@
 #ifndef FL_USE_DMA
 #define FL_USE_DMA 0  // direct-to-LDS staging: correct, measured 3% slower than register staging on gfx950 (r01)
 #endif
+// FL_SPLIT = 0: v_mfma_f32_32x32x2_f32 (fp32 operands on the fp32 matrix path, 256 flop/clk/CU).
+// FL_SPLIT = 6 | 8: every fp32 operand is split EXACTLY into three 8-bit-mantissa pieces x = h + m + l (bf16 by
+// truncation; x - trunc(x) is exact), and the product is assembled from 6 (or 8) of the 9 piece products with
+// v_mfma_f32_32x32x16_bf16 (4096 flop/clk/CU): piece products are exact in fp32, accumulation is fp32 as before.
+// Dropped terms: m*l, l*m, l*l with 6 (<= 2^-23 relative per product, the size of one fp32 rounding); only l*l
+// (2^-32) with 8. 16 k-values cost 6 x 32 = 192 (8 x 32 = 256) matrix-pipe cycles instead of 8 x 64 = 512.
+// Both variants are compiled (template parameter SPLIT = 0 | FL_SPLIT_TERMS); fl_set_gemm_math / FL_GEMM_MATH select
+// at run time.
+#ifndef FL_SPLIT_TERMS
+#define FL_SPLIT_TERMS 6
+#endif
 #ifndef FL_MFMA_ROT
 #define FL_MFMA_ROT 1  // issue consecutive MFMAs on different accumulators
 #endif
 
 namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct Split3 {
+  u32x4_t h, m, l;  // 8 bf16 each: element j of this lane's k-slots (two quarters of a chunk: 4 + 4 floats)
+};
+__device__ __forceinline__ Split3 split3(const float4& q0, const float4& q1) {
+  const float x[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+  float r1[8], r2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xFFFF0000u);    // exact: the low 16 mantissa bits
+    r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xFFFF0000u);  // exact: at most 8 significant bits left
+  }
+  Split3 s;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {  // two bf16 (upper halves of two floats) per word
+    s.h[p] = __builtin_amdgcn_perm(__float_as_uint(x[2 * p + 1]), __float_as_uint(x[2 * p]), 0x07060302u);
+    s.m[p] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * p + 1]), __float_as_uint(r1[2 * p]), 0x07060302u);
+    s.l[p] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * p + 1]), __float_as_uint(r2[2 * p]), 0x07060302u);
+  }
+  return s;
+}
 
 constexpr int BK = 32;
 constexpr int LDK = 36;
@@ -125,8 +159,8 @@ __device__ __forceinline__ float epilogue_value(const GArgs& g, float v, int col
 
 // PATH 0: guarded loads (tails / unaligned operands); 1: branch-free vector loads, per-thread tap decode;
 // 2: as 1 + wave-uniform tap decode (Cin % 32 == 0: a 32-chunk never straddles a tap) kept in scalar registers.
-template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, int PATH>
-__global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
+template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, int PATH, int SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GArgs g) {
   constexpr bool FAST = PATH >= 1;
   constexpr bool CHK = PATH == 2;
   static_assert(WGM * WGN == 4, "4 waves per block");
@@ -451,10 +485,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
 #endif
   };
   float4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  static_assert(!(DMA && SPLIT), "the split path is implemented for the register-staged pipeline only");
+  float4 fa2[TM], fb2[TN], fa3[TM], fb3[TN];
+  // half a chunk (two quarters = this lane's 8 k-slots of a 16-wide bf16 MFMA step): split, then 6 or 8 piece products
+  // per tile, smallest terms first
+  auto frag_mfma2 = [&](const float4 (&a0)[TM], const float4 (&a1)[TM], const float4 (&b0)[TN], const float4 (&b1)[TN]) {
+    Split3 sa[TM], sb[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) sa[tm] = split3(a0[tm], a1[tm]);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) sb[tn] = split3(b0[tn], b1[tn]);
+#define FL_PIECE(pa, pb)                                                                                        \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)          \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, sa[tm].pa),         \
+                                                              __builtin_bit_cast(bf16x8_t, sb[tn].pb), acc[tm][tn], 0, 0, 0);
+    if constexpr (SPLIT >= 8) {
+      FL_PIECE(m, l) FL_PIECE(l, m)
+    }
+    FL_PIECE(l, h) FL_PIECE(h, l) FL_PIECE(m, m) FL_PIECE(m, h) FL_PIECE(h, m) FL_PIECE(h, h)
+#undef FL_PIECE
+  };
+  // On entry (fa0, fb0), (fa1, fb1) hold quarters 0, 1 of chunk kc; on exit those of chunk kc+1.
+  auto iteration_split = [&](int kc, int buf, float4 (&lda)[ANR], float4 (&ldb)[BNR], unsigned& lma, unsigned& lmb,
+                       const float4 (&sta)[ANR], const float4 (&stb)[BNR], unsigned sma, unsigned smb) {
+    const int k2 = kc + 2 < kc_end ? kc + 2 : kc_last;
+    load_A(k2, lda, lma, nullptr);
+    load_B(k2, ldb, lmb, nullptr);
+    const float* Sa = As + buf * A_TILE;
+    const float* Sb = Bs + buf * B_TILE;
+    frag_load(2, Sa, Sb, fa2, fb2);
+    frag_load(3, Sa, Sb, fa3, fb3);
+    frag_mfma2(fa0, fa1, fb0, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_A(buf ^ 1, sta, sma);
+    store_B(buf ^ 1, stb, smb);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    frag_load(0, As + (buf ^ 1) * A_TILE, Bs + (buf ^ 1) * B_TILE, fa0, fb0);
+    frag_load(1, As + (buf ^ 1) * A_TILE, Bs + (buf ^ 1) * B_TILE, fa1, fb1);
+    frag_mfma2(fa2, fa3, fb2, fb3);  // covers the fragment reads of the next chunk
+  };
 
   // one pipeline iteration; LD* = stage receiving chunk kc+2, ST* = stage holding chunk kc+1.
   // On entry (fa0, fb0) hold quarter 0 of chunk kc; on exit they hold quarter 0 of chunk kc+1.
-  auto iteration = [&](int kc, int buf, float4 (&lda)[ANR], float4 (&ldb)[BNR], unsigned& lma, unsigned& lmb,
+  auto iteration_fp32 = [&](int kc, int buf, float4 (&lda)[ANR], float4 (&ldb)[BNR], unsigned& lma, unsigned& lmb,
                        const float4 (&sta)[ANR], const float4 (&stb)[BNR], unsigned sma, unsigned smb) {
     const int k2 = kc + 2 < kc_end ? kc + 2 : kc_last;  // clamped: tail iterations re-load the last chunk (unused)
 #if !(FL_ABLATE & 1)
@@ -483,6 +558,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
     frag_load(0, As + (buf ^ 1) * A_TILE, Bs + (buf ^ 1) * B_TILE, fa0, fb0);
     frag_mfma(fa1, fb1);
   };
+  auto iteration = [&](int kc, int buf, float4 (&lda)[ANR], float4 (&ldb)[BNR], unsigned& lma, unsigned& lmb,
+                       const float4 (&sta)[ANR], const float4 (&stb)[BNR], unsigned sma, unsigned smb) {
+    if constexpr (SPLIT) iteration_split(kc, buf, lda, ldb, lma, lmb, sta, stb, sma, smb);
+    else iteration_fp32(kc, buf, lda, ldb, lma, lmb, sta, stb, sma, smb);
+  };
 
   // Two waves share each SIMD (2 blocks/CU) and run the same program: left alone they fall into lockstep and do
   // their non-MFMA phases together, leaving the matrix pipe idle. A static priority for one of the two
@@ -504,6 +584,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GArgs g) {
     }
     __syncthreads();
     frag_load(0, As, Bs, fa0, fb0);
+    if constexpr (SPLIT) frag_load(1, As, Bs, fa1, fb1);
 
     int kc = kc_begin;
     for (; kc + 1 < kc_end; kc += 2) {
@@ -639,11 +720,11 @@ __global__ void splitk_reduce_kernel(const GArgs g) {
 }
 
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, int FAST>
-int launch_cfg2(GArgs g, int classes, hipStream_t stream) {
+template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, int FAST, int SPLIT>
+int launch_cfg3(GArgs g, int classes, hipStream_t stream) {
   constexpr size_t lds = 2u * (BM + BN) * ((FAST >= 1 && FL_USE_DMA) ? BK : LDK) * sizeof(float);
   static bool attr_set = false;
-  auto kern = gemm_kernel<BM, BN, WGM, WGN, AM, BMODE, FAST>;
+  auto kern = gemm_kernel<BM, BN, WGM, WGN, AM, BMODE, FAST, SPLIT>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -670,6 +751,24 @@ int launch_cfg2(GArgs g, int classes, hipStream_t stream) {
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
   return fl::check_launch("gemm_kernel");
+}
+
+int g_gemm_math = -1;  // -1: read FL_GEMM_MATH on first use; 0: fp32 MFMA; 1: exact bf16 split
+int gemm_math() {
+  if (g_gemm_math < 0) {
+    const char* e = getenv("FL_GEMM_MATH");
+    g_gemm_math = (e && (!strcmp(e, "fp32") || !strcmp(e, "0"))) ? 0 : 1;
+  }
+  return g_gemm_math;
+}
+
+// the guarded slow path (FAST == 0: unaligned operands) always uses the fp32 MFMA; the vectorised paths pick per mode
+template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, int FAST>
+int launch_cfg2(GArgs g, int classes, hipStream_t stream) {
+  if constexpr (FAST >= 1 && !FL_USE_DMA) {
+    if (gemm_math()) return launch_cfg3<BM, BN, WGM, WGN, AM, BMODE, FAST, FL_SPLIT_TERMS>(g, classes, stream);
+  }
+  return launch_cfg3<BM, BN, WGM, WGN, AM, BMODE, FAST, 0>(g, classes, stream);
 }
 
 template <int BM, int BN, int WGM, int WGN, int AM, int BMODE>
@@ -806,6 +905,13 @@ __global__ void conv_inorm_finalize(const float* partial, const float* w, const 
 
 // =====================================================================================
 extern "C" {
+
+int fl_set_gemm_math(int mode) {
+  FL_REQUIRE(mode == 0 || mode == 1, "fl_set_gemm_math: mode %d (0 = fp32 MFMA, 1 = exact bf16 split)", mode);
+  g_gemm_math = mode;
+  return FL_OK;
+}
+int fl_get_gemm_math(void) { return gemm_math(); }
 
 size_t fl_conv2d_fwd_instnorm_workspace_bytes(int B, int Ho, int Wo, int Cout) {
   return ((size_t)B * Ho * Wo / 32 + 1) * 2 * (size_t)Cout * sizeof(float);

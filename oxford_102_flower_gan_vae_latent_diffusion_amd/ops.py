@@ -75,6 +75,16 @@ def new(shape, like):
 
 
 # --------------------------------------------------------------------------- GEMM
+def set_gemm_math(mode):
+    """'split' (default): exact 3-way bf16 split of the fp32 operands, 6 piece products on the bf16 matrix pipe;
+    'fp32': native fp32 MFMA. Applies to every GEMM / conv launched afterwards (re-capture graphs after a change)."""
+    _lib.call("fl_set_gemm_math", {"fp32": 0, "split": 1}[mode] if isinstance(mode, str) else int(mode))
+
+
+def get_gemm_math():
+    return "split" if _lib.load().fl_get_gemm_math() else "fp32"
+
+
 def gemm(A, B, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, bias=None, bias_scale=1.0, R=None,
          r_scale=1.0, r_pre=False, act=ACT_NONE, act_param=0.0, out=None):
     """C[m,n] = epi(sum_k A(m,k) B(n,k)); see flowers_hip.h fl_gemm_f32."""

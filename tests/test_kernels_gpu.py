@@ -394,3 +394,46 @@ def test_multi_axpby(dev):
     ops.multi_axpby(list(zip(ds, dd)), 0.5, 2.0)
     for s, d0, d in zip(src, dst0, dd):
         close(d, 0.5 * s.double() + 2.0 * d0.double(), tol=1e-6)
+
+
+@pytest.fixture
+def each_gemm_math():
+    """run the body once per matrix-core mode; always restore the default"""
+    old = ops.get_gemm_math()
+    yield ("fp32", "split")
+    ops.set_gemm_math(old)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 1024), (512, 128, 4608), (128, 512, 36864)])
+def test_split_mfma_is_fp32_equivalent(dev, each_gemm_math, M, N, K):
+    """The default GEMM math splits each fp32 operand exactly into three bf16 pieces and sums 6 of the 9 piece products
+    on the bf16 matrix pipe. Claim: its error against the exact (fp64) product is of the size of the native fp32-MFMA
+    kernel's own accumulation error - measured here on the same data, several K, and on badly scaled operands."""
+    for scale_a, scale_b in ((1.0, 1.0), (1e-3, 1e4)):
+        A = rnd(M, K, seed=1) * scale_a
+        B = rnd(N, K, seed=2) * scale_b
+        # rows with a wide dynamic range inside one dot product
+        A[:, ::7] *= 64.0
+        B[:, ::5] *= 1.0 / 64.0
+        ref = A.double() @ B.double().t()
+        err = {}
+        for mode in each_gemm_math:
+            ops.set_gemm_math(mode)
+            out = ops.gemm(A.to(dev), B.to(dev), M, N, K)
+            err[mode] = ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+        assert err["split"] <= max(2.0 * err["fp32"], 3e-7), "split %.3e vs fp32 MFMA %.3e (K=%d)" % (err["split"], err["fp32"], K)
+        assert err["fp32"] < 1e-5 and err["split"] < 1e-5
+
+
+def test_conv_fwd_both_gemm_math_modes(dev, each_gemm_math):
+    x = rnd(4, 128, 32, 32, seed=1)
+    w = rnd(128, 128, 3, 3, seed=2, scale=0.05)
+    b = rnd(128, seed=3)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xh, wp = nhwc(x).to(dev), ops.pack_conv_weight(w.to(dev))
+    outs = {}
+    for mode in each_gemm_math:
+        ops.set_gemm_math(mode)
+        outs[mode] = nchw(ops.conv2d_fwd(xh, wp, b.to(dev), 1, 1))
+        close(outs[mode], ref, tol=1e-5)
+    close(outs["split"], outs["fp32"].cpu(), tol=2e-6)
