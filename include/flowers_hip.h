@@ -92,6 +92,17 @@ int fl_conv2d_fwd_instnorm(const float* x, const float* wp, const float* bias, f
                            int Cout, int kh, int kw, int stride, int pad, const float* ln_w, const float* ln_b,
                            float eps, float* scale, float* shift, float* mean, float* rstd, void* ws, size_t ws_bytes,
                            fl_stream_t stream);
+/* Forward conv with a weight that was split into its three bf16 pieces once (fl_split_pack_weight of the packed
+ * [Cout][kh*kw*Cin] weight; fl_split_pack_weight_bytes(N,K) = 6*N*K): the weight fragments go from HBM/L2 straight into
+ * the MFMA operand registers and the VALU-bound inner loop only splits the activations. Needs Cin % 32 == 0 and
+ * Cout % 128 == 0; always uses the split GEMM math. scale != NULL adds the fused LayerNorm2d statistics of
+ * fl_conv2d_fwd_instnorm (same outputs, same workspace, act must be NONE). */
+size_t fl_split_pack_weight_bytes(int N, int K);
+int fl_split_pack_weight(const float* w, void* out, int N, int K, fl_stream_t stream);
+int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias, float* y, int B, int H, int W, int Cin,
+                           int Cout, int kh, int kw, int stride, int pad, int act, float act_param, const float* ln_w,
+                           const float* ln_b, float eps, float* scale, float* shift, float* mean, float* rstd, void* ws,
+                           size_t ws_bytes, fl_stream_t stream);
 /* dx = conv_transpose(dy, w): input gradient of the conv above (stride 1 any
  * kernel; stride 2 only for 4x4 p1).  dy:(B,Ho,Wo,Cout) -> dx:(B,H,W,Cin).
  * wp is the SAME packed weight as the forward. */

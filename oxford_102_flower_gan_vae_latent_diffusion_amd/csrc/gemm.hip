@@ -54,6 +54,13 @@ struct Split3 {
 };
 __device__ __forceinline__ Split3 split3(const float4& q0, const float4& q1) {
   const float x[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#if FL_ABLATE & 16
+  Split3 t;  // timing-only: no and/sub chain, the three pieces are the same truncation
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    t.h[p] = t.m[p] = t.l[p] = __builtin_amdgcn_perm(__float_as_uint(x[2 * p + 1]), __float_as_uint(x[2 * p]), 0x07060302u);
+  return t;
+#endif
   float r1[8], r2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -74,7 +81,12 @@ constexpr int BK = 32;
 constexpr int LDK = 36;
 
 enum { A_KC_PLAIN = 0, A_KC_CONV = 1, A_KC_TCONV = 2, A_KS_PLAIN = 3 };
-enum { B_KC_PLAIN = 0, B_KS_PLAIN = 1, B_KS_TAPFLIP = 2, B_KS_TAPCLS = 3, B_KS_IM2COL = 4 };
+enum { B_KC_PLAIN = 0, B_KS_PLAIN = 1, B_KS_TAPFLIP = 2, B_KS_TAPCLS = 3, B_KS_IM2COL = 4, B_FRAGS = 5 };
+// B_FRAGS (split math only): the B operand (weights, constant over the batch) was split into its three bf16 pieces
+// ONCE, on the host side of the step (fl_split_pack_weight), and laid out in MFMA-fragment order:
+//   [16-wide k group][32-column tile][piece h|m|l][lane 0..63][8 bf16]   (k slots of a lane as in frag_load)
+// so a wave fetches a B fragment with one coalesced 1 KiB global_load_dwordx4 straight into the MFMA operand
+// registers: no LDS image, no staging registers and - the point - no split work for B in the VALU-bound inner loop.
 enum { OUT_ROWMAJOR = 0, OUT_NCHW = 1, OUT_TCONV = 2 };
 
 struct GArgs {
@@ -168,7 +180,9 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GArgs g)
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int ANR = BM / 32, BNR = BN / 32;  // float4 per thread per chunk
   constexpr bool A_KS = (AM == A_KS_PLAIN);
-  constexpr bool B_KS = (BMODE != B_KC_PLAIN);
+  constexpr bool B_FR = (BMODE == B_FRAGS);
+  static_assert(!B_FR || (SPLIT == 6 && !A_KS), "B_FRAGS needs the 6-term split math and a K-contiguous A");
+  constexpr bool B_KS = (BMODE != B_KC_PLAIN) && !B_FR;
   // PATH >= 1 stages global -> LDS directly (LDS-DMA, global_load_lds_dwordx4): no VGPR staging, no ds_write, no
   // zero-selects. A wave-instruction writes 1 KiB contiguously (wave-uniform base + lane*16), so the K-contiguous
   // image is UNPADDED [rows][32] with an XOR swizzle on the 16-byte chunk index applied on the SOURCE side
@@ -325,7 +339,9 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GArgs g)
 
   auto load_B = [&](int kc, float4 (&regs)[BNR], unsigned& mask, float* dst) {
     mask = 0u;
-    if constexpr (BMODE == B_KC_PLAIN) {
+    if constexpr (B_FR) {
+      return;  // B never passes through the staging registers / LDS in this mode
+    } else if constexpr (BMODE == B_KC_PLAIN) {
       const int k = kc * BK + kq;
       const int kleft = g.K - k;
 #pragma unroll
@@ -407,6 +423,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GArgs g)
     }
   };
   auto store_B = [&](int buf, const float4 (&regs)[BNR], unsigned mask) {
+    if constexpr (B_FR) return;
     float* S = Bs + buf * B_TILE;
 #pragma unroll
     for (int r = 0; r < BNR; ++r) {
@@ -453,6 +470,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GArgs g)
     }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
+      if constexpr (B_FR) continue;
       const int row = wc * WN + tn * 32 + li;
       if constexpr (!B_KS) {
         if constexpr (DMA) bf[tn] = *reinterpret_cast<const float4*>(Sb + row * BK + (((2 * q + lh) ^ ((row >> 1) & 7)) << 2));
@@ -558,9 +576,77 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GArgs g)
     frag_load(0, As + (buf ^ 1) * A_TILE, Bs + (buf ^ 1) * B_TILE, fa0, fb0);
     frag_mfma(fa1, fb1);
   };
+  // ---- B_FRAGS: pre-split B fragments straight from global memory, two plane sets alternating by half chunk ----
+  u32x4_t bpA[TN][3], bpB[TN][3];
+  const int nt32 = g.N >> 5;
+  const int g16_last = 2 * kc_end - 1;
+  auto load_bp = [&](int g16, u32x4_t (&bp)[TN][3]) {
+#if FL_ABLATE & 8
+    if (g16 > 2 * kc_begin + 1) return;  // timing-only: B pieces are fetched once
+#endif
+    g16 = g16 < g16_last ? g16 : g16_last;  // clamped: the tail re-reads the last group (never consumed)
+    const u32x4_t* base = reinterpret_cast<const u32x4_t*>(g.B) +
+                          ((size_t)g16 * nt32 + ((tile_n0 + wc * WN) >> 5)) * (3 * 64) + lane;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bp[tn][p] = base[(tn * 3 + p) * 64];
+  };
+  // Software-pipelined inside the wave: the 24 MFMAs of one half chunk (on pieces split earlier) and the VALU split of
+  // the NEXT half's A fragments sit in one scheduling region and are interleaved 1 MFMA : 8 VALU, so the matrix pipe
+  // works while the vector pipe prepares its next operands (a wave issues in order, but an MFMA executes for 32
+  // cycles after its 4-cycle issue). sa01 / sa23 are the split A pieces of quarters (0,1) / (2,3).
+  Split3 sa01[TM], sa23[TM];
+  auto mfma_and_split = [&](const Split3 (&sa)[TM], const u32x4_t (&bp)[TN][3], Split3 (&sn)[TM], const float4 (&n0)[TM],
+                            const float4 (&n1)[TM]) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) sn[tm] = split3(n0[tm], n1[tm]);
+#define FL_PIECE(pa, pi)                                                                                        \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)          \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, sa[tm].pa),         \
+                                                              __builtin_bit_cast(bf16x8_t, bp[tn][pi]), acc[tm][tn], 0, 0, 0);
+#if FL_ABLATE & 32
+    FL_PIECE(h, 0)
+#else
+    FL_PIECE(l, 0) FL_PIECE(h, 2) FL_PIECE(m, 1) FL_PIECE(m, 0) FL_PIECE(h, 1) FL_PIECE(h, 0)
+#endif
+#undef FL_PIECE
+    // pattern for the scheduler: 4 MFMAs up front (cover the LDS latency of the fragments being split), then
+    // 1 MFMA : 8 VALU until the MFMAs run out
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+    for (int i = 0; i < 6 * TM * TN - 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+  };
+  // On entry sa01 holds the split A pieces of quarters 0, 1 of chunk kc and bpA the B pieces of its first half.
+  auto iteration_frags = [&](int kc, int buf, float4 (&lda)[ANR], unsigned& lma, const float4 (&sta)[ANR], unsigned sma) {
+    const int k2 = kc + 2 < kc_end ? kc + 2 : kc_last;
+    load_A(k2, lda, lma, nullptr);
+    load_bp(2 * kc + 1, bpB);
+    const float* Sa = As + buf * A_TILE;
+    frag_load(2, Sa, Sa, fa2, fb2);
+    frag_load(3, Sa, Sa, fa3, fb3);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_and_split(sa01, bpA, sa23, fa2, fa3);
+    __builtin_amdgcn_sched_barrier(0);
+    store_A(buf ^ 1, sta, sma);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_bp(2 * kc + 2, bpA);
+    frag_load(0, As + (buf ^ 1) * A_TILE, As, fa0, fb0);
+    frag_load(1, As + (buf ^ 1) * A_TILE, As, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_and_split(sa23, bpB, sa01, fa0, fa1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   auto iteration = [&](int kc, int buf, float4 (&lda)[ANR], float4 (&ldb)[BNR], unsigned& lma, unsigned& lmb,
                        const float4 (&sta)[ANR], const float4 (&stb)[BNR], unsigned sma, unsigned smb) {
-    if constexpr (SPLIT) iteration_split(kc, buf, lda, ldb, lma, lmb, sta, stb, sma, smb);
+    if constexpr (B_FR) iteration_frags(kc, buf, lda, lma, sta, sma);
+    else if constexpr (SPLIT) iteration_split(kc, buf, lda, ldb, lma, lmb, sta, stb, sma, smb);
     else iteration_fp32(kc, buf, lda, ldb, lma, lmb, sta, stb, sma, smb);
   };
 
@@ -585,6 +671,11 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GArgs g)
     __syncthreads();
     frag_load(0, As, Bs, fa0, fb0);
     if constexpr (SPLIT) frag_load(1, As, Bs, fa1, fb1);
+    if constexpr (B_FR) {
+      load_bp(2 * kc_begin, bpA);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) sa01[tm] = split3(fa0[tm], fa1[tm]);
+    }
 
     int kc = kc_begin;
     for (; kc + 1 < kc_end; kc += 2) {
@@ -706,6 +797,22 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GArgs g)
   }
 }
 
+// fp32 [N][K] -> B_FRAGS layout (see the enum): one thread per (16-wide k group, 32-column tile, lane)
+__global__ void split_pack_kernel(const float* __restrict__ w, u32x4_t* __restrict__ out, int N, int K) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nt = N >> 5;
+  if (i >= (long long)(K >> 4) * nt * 64) return;
+  const int lane = (int)(i & 63), lr = lane & 31, lh = lane >> 5;
+  const long long gt = i >> 6;
+  const int t = (int)(gt % nt), g16 = (int)(gt / nt);
+  const float* row = w + (long long)(32 * t + lr) * K + 16 * g16 + 4 * lh;  // k slots: 4*lh + j and 8 + 4*lh + j
+  const Split3 s = split3(*reinterpret_cast<const float4*>(row), *reinterpret_cast<const float4*>(row + 8));
+  u32x4_t* o = out + (gt * 3) * 64 + lane;
+  o[0] = s.h;
+  o[64] = s.m;
+  o[128] = s.l;
+}
+
 // split-K combine + epilogue (row-major outputs only)
 __global__ void splitk_reduce_kernel(const GArgs g) {
   const long long total = (long long)g.M * g.N;
@@ -722,7 +829,7 @@ __global__ void splitk_reduce_kernel(const GArgs g) {
 // ------------------------------------------------------------------------------------
 template <int BM, int BN, int WGM, int WGN, int AM, int BMODE, int FAST, int SPLIT>
 int launch_cfg3(GArgs g, int classes, hipStream_t stream) {
-  constexpr size_t lds = 2u * (BM + BN) * ((FAST >= 1 && FL_USE_DMA) ? BK : LDK) * sizeof(float);
+  constexpr size_t lds = 2u * (BM + (BMODE == B_FRAGS ? 0 : BN)) * ((FAST >= 1 && FL_USE_DMA) ? BK : LDK) * sizeof(float);
   static bool attr_set = false;
   auto kern = gemm_kernel<BM, BN, WGM, WGN, AM, BMODE, FAST, SPLIT>;
   if (!attr_set) {
@@ -905,6 +1012,51 @@ __global__ void conv_inorm_finalize(const float* partial, const float* w, const 
 
 // =====================================================================================
 extern "C" {
+
+size_t fl_split_pack_weight_bytes(int N, int K) { return (size_t)N * K * 6; }
+
+// w: [N][K] fp32 (K-contiguous: a packed conv weight or an nn.Linear weight), N % 32 == 0, K % 16 == 0
+int fl_split_pack_weight(const float* w, void* out, int N, int K, fl_stream_t stream) {
+  FL_REQUIRE(w && out && N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, "fl_split_pack_weight: N=%d (mult. of 32), K=%d (mult. of 16)", N, K);
+  const long long total = (long long)(K / 16) * (N / 32) * 64;
+  hipLaunchKernelGGL(split_pack_kernel, dim3(fl::cdiv(total, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w,
+                     reinterpret_cast<u32x4_t*>(out), N, K);
+  return fl::check_launch("split_pack_kernel");
+}
+
+// conv forward with a pre-split weight (B_FRAGS): 128x128 tiles, Cin % 32 == 0, Cout % 128 == 0; optional fused
+// LayerNorm2d statistics like fl_conv2d_fwd_instnorm (ln_w/ln_b/scale/shift may all be NULL: plain conv + bias + act)
+int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias, float* y, int B, int H, int W, int Cin,
+                           int Cout, int kh, int kw, int stride, int pad, int act, float act_param, const float* ln_w,
+                           const float* ln_b, float eps, float* scale, float* shift, float* mean, float* rstd, void* ws,
+                           size_t ws_bytes, fl_stream_t stream) {
+  FL_REQUIRE(x && wsplit && y, "fl_conv2d_fwd_presplit: null operand");
+  FL_REQUIRE(Cin % 32 == 0 && Cout % 128 == 0 && is_vec(x, Cin), "fl_conv2d_fwd_presplit: needs Cin %% 32 == 0, Cout %% 128 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+  const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+  const int HW = Ho * Wo;
+  FL_REQUIRE(Ho > 0 && Wo > 0, "fl_conv2d_fwd_presplit: empty output");
+  const bool stats = scale != nullptr;
+  if (stats) {
+    FL_REQUIRE(shift && act == FL_ACT_NONE && HW % 64 == 0, "fl_conv2d_fwd_presplit: fused statistics need shift, act NONE, H*W %% 64 == 0");
+    FL_REQUIRE(ws && ws_bytes >= fl_conv2d_fwd_instnorm_workspace_bytes(B, Ho, Wo, Cout), "fl_conv2d_fwd_presplit: workspace too small");
+  }
+  GArgs g = base_args();
+  g.M = B * HW; g.N = Cout; g.K = kh * kw * Cin;
+  g.A = x; g.a_vec = 1;
+  g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.kw = kw; g.stride = stride; g.pad = pad;
+  g.B = reinterpret_cast<const float*>(wsplit); g.ldb = g.K; g.b_vec = 1;
+  g.C = y; g.ldc = Cout; g.out_mode = OUT_ROWMAJOR;
+  g.bias = bias; g.ldr = Cout; g.act = act; g.act_param = act_param;
+  g.stats = stats ? reinterpret_cast<float*>(ws) : nullptr;
+  g.splitk = 1;
+  g.chunks_per_split = fl::cdiv(g.K, BK);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int rc = launch_cfg3<128, 128, 2, 2, A_KC_CONV, B_FRAGS, 2, 6>(g, 1, s);
+  if (rc || !stats) return rc;
+  hipLaunchKernelGGL(conv_inorm_finalize, dim3(fl::cdiv((long long)B * Cout, 256)), dim3(256), 0, s, g.stats, ln_w, ln_b, eps,
+                     scale, shift, mean, rstd, B, HW, Cout, HW / 64);
+  return fl::check_launch("conv_inorm_finalize");
+}
 
 int fl_set_gemm_math(int mode) {
   FL_REQUIRE(mode == 0 || mode == 1, "fl_set_gemm_math: mode %d (0 = fp32 MFMA, 1 = exact bf16 split)", mode);

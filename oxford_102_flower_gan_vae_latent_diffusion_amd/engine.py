@@ -34,8 +34,35 @@ class PackCache:
         return self.get(("conv", id(conv)), [w], lambda: ops.pack_conv_weight(w.detach(), ipad))
 
 
+    def conv_split(self, conv):
+        """nn.Conv2d weight split once into its three bf16 pieces in MFMA-fragment order (ops.split_pack_weight) for the
+        inference convs of the split GEMM math -> (pieces, (O, kh, kw, Ipad))."""
+        w = conv.weight
+
+        def make():
+            wp = self.conv(conv)
+            return ops.split_pack_weight(wp), tuple(wp.shape)
+
+        return self.get(("convsplit", id(conv)), [w], make)
+
+
 def _d(p):
     return p.detach() if p is not None else None
+
+
+def conv_ln_infer(x, conv, ln, stride, pad, pk):
+    """inference conv + fused LayerNorm2d statistics -> (y, scale, shift); weights pre-split when the layer qualifies."""
+    B, H, W, Cin = x.shape
+    Cout, _, kh, kw = conv.weight.shape
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if ops.get_gemm_math() == "split" and ops.presplit_ok(Cin, Cout, Ho * Wo):
+        ws, geom = pk.conv_split(conv)
+        y, (sc, sh, _, _) = ops.conv2d_fwd_presplit(x, ws, geom, _d(conv.bias), stride, pad, ln_w=_d(ln.weight),
+                                                    ln_b=_d(ln.bias), eps=ln.eps)
+    else:
+        y, (sc, sh, _, _) = ops.conv2d_fwd_instnorm(x, pk.conv(conv), _d(conv.bias), stride, pad, _d(ln.weight), _d(ln.bias),
+                                                    ln.eps)
+    return y, sc, sh
 
 
 # ----------------------------------------------------------------------------- VAE blocks (inference)
@@ -49,11 +76,9 @@ def ca_gate(ca, pooled):
 
 def resblock_infer(x, rb, pk):
     """ResidualBlock.forward (v2:170-178), NHWC, no saved state. 2 convs + 2 stats passes + 3 streaming passes."""
-    y1, (sc, sh, _, _) = ops.conv2d_fwd_instnorm(x, pk.conv(rb.conv1), _d(rb.conv1.bias), 1, 1, _d(rb.ln1.weight),
-                                                 _d(rb.ln1.bias), rb.ln1.eps)
+    y1, sc, sh = conv_ln_infer(x, rb.conv1, rb.ln1, 1, 1, pk)
     a1 = ops.affine_act(y1, sc, sh, act=SW, out=y1)
-    y2, (sc2, sh2, _, _) = ops.conv2d_fwd_instnorm(a1, pk.conv(rb.conv2), _d(rb.conv2.bias), 1, 1, _d(rb.ln2.weight),
-                                                   _d(rb.ln2.bias), rb.ln2.eps)
+    y2, sc2, sh2 = conv_ln_infer(a1, rb.conv2, rb.ln2, 1, 1, pk)
     # avg_pool(LayerNorm2d(y)) == ln2.bias exactly (normalised maps have zero spatial mean), so the
     # channel-attention gate (v2:65-66) is one (C,) vector shared by the batch: no pooling pass.
     # ... and a function of the weights only: computed once per weight version, not per batch.
@@ -81,8 +106,7 @@ def encoder_infer(enc, x):
     feats = [h]
     for i in (1, 2, 3):
         dn, rb = getattr(enc, "down%d" % i), getattr(enc, "res%d" % i)
-        y, (sc, sh, _, _) = ops.conv2d_fwd_instnorm(h, pk.conv(dn[0]), _d(dn[0].bias), 2, 1, _d(dn[1].weight),
-                                                    _d(dn[1].bias), dn[1].eps)
+        y, sc, sh = conv_ln_infer(h, dn[0], dn[1], 2, 1, pk)
         h = ops.affine_act(y, sc, sh, act=SW, out=y)
         h = resblock_infer(h, rb, pk)
         feats.append(h)

@@ -203,6 +203,42 @@ def conv2d_fwd_instnorm(x, wp, bias, stride, pad, ln_w, ln_b, eps=1e-5):
     return y, (scale, shift, mean, rstd)
 
 
+def split_pack_weight(wp):
+    """packed conv weight [O][kh][kw][I] (or any [N][K] K-contiguous matrix) -> its three bf16 pieces in MFMA-fragment
+    order (uint8 tensor of 6*N*K bytes) for conv2d_fwd_presplit. N % 32 == 0, K % 16 == 0."""
+    _chk(wp)
+    N = wp.shape[0]
+    K = wp.numel() // N
+    out = torch.empty(_lib.load().fl_split_pack_weight_bytes(N, K), dtype=torch.uint8, device=wp.device)
+    _lib.call("fl_split_pack_weight", _p(wp), _p(out), N, K, _stream())
+    return out
+
+
+def conv2d_fwd_presplit(x, wsplit, geom, bias, stride, pad, act=ACT_NONE, act_param=0.0, ln_w=None, ln_b=None, eps=1e-5,
+                        out=None):
+    """conv forward with a pre-split weight (geom = (Cout, kh, kw, Cin) of the packed weight it was made from).
+    With ln_w/ln_b: also the fused LayerNorm2d statistics -> (y, (scale, shift, mean, rstd)); else y."""
+    _chk(x, bias, ln_w, ln_b, out)
+    B, H, W, Cin = x.shape
+    Cout, kh, kw, Ci2 = geom
+    assert Ci2 == Cin
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    y = out if out is not None else new((B, Ho, Wo, Cout), x)
+    if ln_w is None:
+        _lib.call("fl_conv2d_fwd_presplit", _p(x), _p(wsplit), _p(bias), _p(y), B, H, W, Cin, Cout, kh, kw, stride, pad, act,
+                  float(act_param), None, None, float(eps), None, None, None, None, None, 0, _stream())
+        return y
+    scale, shift, mean, rstd = (new((B, Cout), x) for _ in range(4))
+    wsp, wsn = _ws(_lib.load().fl_conv2d_fwd_instnorm_workspace_bytes(B, Ho, Wo, Cout), x)
+    _lib.call("fl_conv2d_fwd_presplit", _p(x), _p(wsplit), _p(bias), _p(y), B, H, W, Cin, Cout, kh, kw, stride, pad, act,
+              float(act_param), _p(ln_w), _p(ln_b), float(eps), _p(scale), _p(shift), _p(mean), _p(rstd), wsp, wsn, _stream())
+    return y, (scale, shift, mean, rstd)
+
+
+def presplit_ok(Cin, Cout, HoWo):
+    return Cin % 32 == 0 and Cout % 128 == 0 and HoWo % 64 == 0
+
+
 def conv2d_dgrad(dy, wp, in_hw, stride, pad, out=None):
     _chk(dy, wp, out)
     B, Ho, Wo, Cout = dy.shape

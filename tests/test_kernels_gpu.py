@@ -437,3 +437,28 @@ def test_conv_fwd_both_gemm_math_modes(dev, each_gemm_math):
         outs[mode] = nchw(ops.conv2d_fwd(xh, wp, b.to(dev), 1, 1))
         close(outs[mode], ref, tol=1e-5)
     close(outs["split"], outs["fp32"].cpu(), tol=2e-6)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,HW,k,s,p", [(2, 128, 128, 32, 3, 1, 1), (3, 64, 128, 64, 4, 2, 1), (1, 256, 256, 16, 3, 1, 1),
+                                                 (2, 256, 512, 16, 4, 2, 1)])
+def test_conv_fwd_presplit_weight(dev, B, Cin, Cout, HW, k, s, p):
+    """pre-split weight fragments (B_FRAGS) give the same convolution as the in-kernel split and as fp64 F.conv2d,
+    with and without the fused LayerNorm2d statistics."""
+    x = rnd(B, Cin, HW, HW, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=0.05)
+    bias = rnd(Cout, seed=3)
+    lw, lb = rnd(Cout, seed=4), rnd(Cout, seed=5)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride=s, padding=p)
+    xh = nhwc(x).to(dev)
+    wp = ops.pack_conv_weight(w.to(dev))
+    ws = ops.split_pack_weight(wp)
+    geom = tuple(wp.shape)
+    y = ops.conv2d_fwd_presplit(xh, ws, geom, bias.to(dev), s, p, act=ops.ACT_RELU)
+    close(nchw(y), torch.relu(ref), tol=1e-5)
+    y2, (sc, sh, mean, rstd) = ops.conv2d_fwd_presplit(xh, ws, geom, bias.to(dev), s, p, ln_w=lw.to(dev), ln_b=lb.to(dev))
+    close(nchw(y2), ref, tol=1e-5)
+    y3, (sc3, sh3, _, _) = ops.conv2d_fwd_instnorm(xh, wp, bias.to(dev), s, p, lw.to(dev), lb.to(dev), 1e-5)
+    close(y2, y3.cpu(), tol=2e-6)
+    close(sc, sc3.cpu(), tol=1e-5)
+    close(sh, sh3.cpu(), tol=1e-5)
+    close(mean, ref.mean((2, 3)), tol=1e-5)

@@ -30,11 +30,16 @@ def main():
         bias = torch.zeros(Co, device=dev)
         Ho = (H + 2 * p - k) // s + 1
         y = torch.empty(b, Ho, Ho, Co, device=dev)
-        ops.conv2d_fwd(x, w, bias, s, p, out=y)
+        if os.environ.get("PRESPLIT"):  # weights split once (B_FRAGS): the inference-encoder path
+            wsp, geom = ops.split_pack_weight(w), tuple(w.shape)
+            run = lambda: ops.conv2d_fwd_presplit(x, wsp, geom, bias, s, p, out=y)
+        else:
+            run = lambda: ops.conv2d_fwd(x, w, bias, s, p, out=y)
+        run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.conv2d_fwd(x, w, bias, s, p, out=y)
+            run()
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1) / reps
