@@ -269,7 +269,7 @@ def main():
                 "achieved_over_fp32_mfma_peak": r["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                 # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, averaged over the 9
                 # launches at B=256; profiles/r01_conv_kernel_pmc.md). Not re-measured live: PMC needs the profiler.
-                "traffic": 4.08e8 if B == 256 else None,
+                "traffic": (4.4e8 if split else 4.08e8) if B == 256 else None,
                 "algorithmic_bytes_per_launch": 1.86e8 if B == 256 else None,
                 "avg_launch_ms": r["avg_ms"],
                 "algorithmic_gflop_per_launch": r["flop_per_launch"] / 1e9,
