@@ -334,7 +334,8 @@ typedef struct fl_pphase {
 /* sizeof(fl_pjob) / sizeof(fl_pphase) as compiled: the host-side builder asserts its packing against these */
 int fl_program_job_bytes(void);
 int fl_program_phase_bytes(void);
-/* tiles a job occupies (GEMM: ceil(M/32)*(N/32); ROWNORM: ceil(M/4); SINUSOID: ceil(M*N/2/256); GATHER, PSAMPLE: ceil(M*N/1024));
+/* tiles a job occupies = ceil(M/32) row tiles x tiles per row tile (GEMM: N/32; ROWNORM: 8; SINUSOID: ceil(32*N/2/256);
+ * GATHER, PSAMPLE: ceil(32*N/4/256));
  * negative fl_status if the job violates the shape rules above. `job` is a HOST pointer. */
 int fl_program_job_tiles(const void* job);
 /* Bytes of the barrier area `sync` (arrival counters spread over memory channels, departures, abort flag). */
@@ -345,8 +346,11 @@ int fl_program_sync_bytes(void);
  * reused across runs (abort word != 0 afterwards: the run is void and the caller must zero `sync`). max_blocks: 0 =
  * one block per CU. Concurrent runs must not share `sync`; two programs running at once on one device may each wait
  * for CUs the other holds until the barrier timeout fires. `post`: HOST pointer to an fl_program_post, or NULL. */
+#define FL_PROG_XCD_LOCAL 1 /* flags: every job of the program works on the same batch rows (same M, no broadcast producer):
+                              32-row tiles are dealt to the XCDs (by HW_REG_XCC_ID census), phases hand data over through
+                              the XCD's own L2 and end in a barrier among that XCD's blocks only */
 int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_jobs, const void* const* io, int n_io,
-                   void* sync, int max_blocks, const void* post, fl_stream_t stream);
+                   void* sync, int max_blocks, int flags, const void* post, fl_stream_t stream);
 
 #ifdef __cplusplus
 }

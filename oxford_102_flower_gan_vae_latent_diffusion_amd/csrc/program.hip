@@ -75,27 +75,21 @@ __device__ __forceinline__ float4 ld4g(const float* p) {
 // Outputs are stored write-through (sc0 sc1: at memory, visible device-wide, once acknowledged - vmcnt), so the barrier
 // needs no L2 write-back (buffer_wbl2 costs 1.2-2.3 us per block and phase). -DFL_PROG_WT_STORES=0 restores plain stores
 // + a release fence per block.
-#ifndef FL_PROG_WT_STORES
-#define FL_PROG_WT_STORES 1
-#endif
+// XCD-local programs (see program_kernel<true>) hand data over through the XCD's own L2 only: plain stores.
 __device__ __forceinline__ f32x4v ld4gv(const float* p) { return *(gf4_t*)(p); }
 __device__ __forceinline__ float ld1g(const float* p) { return *(__attribute__((address_space(1))) const float*)(p); }
+template <bool WT>
 __device__ __forceinline__ void st1g(float* p, float v) {
-#if FL_PROG_WT_STORES
-  asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-#else
-  *(__attribute__((address_space(1))) float*)(p) = v;
-#endif
+  if constexpr (WT) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  else *(__attribute__((address_space(1))) float*)(p) = v;
 }
 __device__ __forceinline__ long long ldi64g(const long long* p) { return *(__attribute__((address_space(1))) const long long*)(p); }
+template <bool WT>
 __device__ __forceinline__ void st4g(float* p, const float4& v) {
   f32x4v t;
   t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
-#if FL_PROG_WT_STORES
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
-#else
-  *(gf4w_t*)(p) = t;
-#endif
+  if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+  else *(gf4w_t*)(p) = t;
 }
 
 // A job descriptor is read from the LDS copy into scalar registers (every field is wave-uniform); unused fields fold away.
@@ -149,17 +143,8 @@ struct Stage {
   f32x4v a[8], w[8];
 };
 
-__device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int lt, const ProgIO& io, float* smem) {
-  const int nct = jb.N / TS, nrt = (jb.M + TS - 1) / TS;
-  int ct, rt;
-  if ((nct & 7) == 0) {  // tile lt runs on XCD lt%8 (round-robin block placement): keep a weight column block on one XCD
-    const int x = lt & 7, j = lt >> 3, jc = j / nrt;
-    ct = x + 8 * jc;
-    rt = j - jc * nrt;
-  } else {
-    ct = lt / nrt;
-    rt = lt - ct * nrt;
-  }
+template <bool WT>
+__device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, const ProgIO& io, float* smem) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
   const int kq4 = lane * 4;  // this thread's k offset inside a chunk row (a wave covers one whole 256-wide row slice)
@@ -315,15 +300,16 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int lt, const ProgI
     if (jb.R) {
       v.x += e_r.x; v.y += e_r.y; v.z += e_r.z; v.w += e_r.w;
     }
-    st4g(wp(jb.C, io) + (long long)gr * jb.ldc + gc, v);
+    st4g<WT>(wp(jb.C, io) + (long long)gr * jb.ldc + gc, v);
   }
   __syncthreads();  // the partial tiles alias stage 0 of the next tile
 }
 
 // Row LayerNorm (+mask, act, residual, gated extra) and an optional second LayerNorm of the result; one wave per row.
-__device__ __forceinline__ void rownorm_tile(const fl_pjob& jb, int lt, const ProgIO& io) {
+template <bool WT>
+__device__ __forceinline__ void rownorm_tile(const fl_pjob& jb, int row4, const ProgIO& io) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int row = lt * 4 + w;
+  const int row = row4 + w;
   if (row >= jb.M) return;
   const int D = jb.N, nv = D >> 8;  // float4 per lane (D % 256 == 0, D <= 1024)
   const float* x = rp(jb.A[0], io) + (long long)row * jb.lda[0];
@@ -380,7 +366,7 @@ __device__ __forceinline__ void rownorm_tile(const fl_pjob& jb, int lt, const Pr
         const float4 k = ld4g(gx + o);
         y.x += sg * k.x; y.y += sg * k.y; y.z += sg * k.z; y.w += sg * k.w;
       }
-      if (y1) st4g(y1 + o, y);
+      if (y1) st4g<WT>(y1 + o, y);
       v[i] = y;
       s2 += (y.x + y.y) + (y.z + y.w);
     }
@@ -409,30 +395,33 @@ __device__ __forceinline__ void rownorm_tile(const fl_pjob& jb, int lt, const Pr
       y.y = (v[i].y - m2) * r2 * ww.y + bb.y;
       y.z = (v[i].z - m2) * r2 * ww.z + bb.z;
       y.w = (v[i].w - m2) * r2 * ww.w + bb.w;
-      st4g(y2 + o, y);
+      st4g<WT>(y2 + o, y);
     }
   }
 }
 
-__device__ __forceinline__ void sinusoid_tile(const fl_pjob& jb, int lt, const ProgIO& io) {
+// elementwise kinds: tile k of the rows [r0, r1)
+template <bool WT>
+__device__ __forceinline__ void sinusoid_tile(const fl_pjob& jb, int r0, int r1, int k, const ProgIO& io) {
   const int half = jb.N >> 1;
-  const int i = lt * 256 + threadIdx.x;
-  if (i >= jb.M * half) return;
+  const int i = r0 * half + k * 256 + threadIdx.x;
+  if (i >= r1 * half) return;
   const int b = i / half, j = i - b * half;
   const long long* t = reinterpret_cast<const long long*>(rp(jb.A[0], io));
   const float a = (float)ldi64g(t + (long long)b * jb.lda[0]) * ld1g(rp(jb.W[0], io) + j);
   float* out = wp(jb.C, io) + (long long)b * jb.ldc;
-  st1g(out + j, sinf(a));
-  st1g(out + half + j, cosf(a));
+  st1g<WT>(out + j, sinf(a));
+  st1g<WT>(out + half + j, cosf(a));
 }
 
-__device__ __forceinline__ void gather_tile(const fl_pjob& jb, int lt, const ProgIO& io) {
-  const int i = (lt * 256 + threadIdx.x) * 4;
-  if (i >= jb.M * jb.N) return;
+template <bool WT>
+__device__ __forceinline__ void gather_tile(const fl_pjob& jb, int r0, int r1, int k, const ProgIO& io) {
+  const int i = r0 * jb.N + (k * 256 + threadIdx.x) * 4;
+  if (i >= r1 * jb.N) return;
   const int b = i / jb.N, d = i - b * jb.N;
   const long long* idx = reinterpret_cast<const long long*>(rp(jb.W[0], io));
   const float4 v = ld4g(rp(jb.A[0], io) + ldi64g(idx + b) * jb.lda[0] + d);
-  st4g(wp(jb.C, io) + (long long)b * jb.ldc + d, v);
+  st4g<WT>(wp(jb.C, io) + (long long)b * jb.ldc + d, v);
 }
 
 // ---- Philox4x32-10, the same stream as fl_philox_fill (elementwise.hip): 4 normals per counter -------------------
@@ -461,10 +450,10 @@ __device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint64_t ctr) {
 }
 
 // DDPM reverse update (v2:585-592; same arithmetic as p_sample_kernel in elementwise.hip), float4 per thread.
-__device__ __forceinline__ void psample_tile(const fl_pjob& jb, int lt, const ProgIO& io) {
-  const long long i4 = (long long)lt * 256 + threadIdx.x;  // float4 index == Philox counter offset
-  const long long n = (long long)jb.M * jb.N;
-  if (i4 * 4 >= n) return;
+template <bool WT>
+__device__ __forceinline__ void psample_tile(const fl_pjob& jb, int r0, int r1, int k, const ProgIO& io) {
+  const long long i4 = ((long long)r0 * jb.N >> 2) + (long long)k * 256 + threadIdx.x;  // float4 index == Philox counter offset
+  if (i4 * 4 >= (long long)r1 * jb.N) return;
   const int t = (int)ldi64g(reinterpret_cast<const long long*>(rp(jb.aux[2], io)));
   const float a = ld1g(rp(jb.W[0], io) + t), ab = ld1g(rp(jb.W[1], io) + t), be = ld1g(rp(jb.W[2], io) + t);
   const float coef = (1.f - a) / sqrtf(1.f - ab), sa = sqrtf(a), sg = sqrtf(be);
@@ -485,24 +474,19 @@ __device__ __forceinline__ void psample_tile(const fl_pjob& jb, int lt, const Pr
     }
     m.x += sg * z.x; m.y += sg * z.y; m.z += sg * z.z; m.w += sg * z.w;
   }
-  st4g(wp(jb.C, io) + i4 * 4, m);
+  st4g<WT>(wp(jb.C, io) + i4 * 4, m);
 }
 
 // Device-wide barrier for a fully resident grid. Arrival counters sync[g*CTR_STRIDE] (g = block & 7; monotone over the
 // run), departures sync[NCTR*CTR_STRIDE], abort flag sync[NCTR*CTR_STRIDE + 16]. Returns false if the run is dead
 // (timeout here or in another block): every wave then leaves.
 __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, bool acquire, int* s_ok) {
-#if FL_PROG_WT_STORES
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // asm stores are invisible to the compiler's counters
-#endif
   __syncthreads();  // every wave's stores have left the CU (s_waitcnt vmcnt(0) precedes s_barrier)
   if (threadIdx.x == 0) {
     // ONE release per block: write the XCD's dirty L2 lines back (the block's stores are in L2 by now), then arrive.
     // Polling is relaxed (plain sc1 loads): an acquire per poll would invalidate the L2 on every iteration.
     FL_STAMP(3);
-#if !FL_PROG_WT_STORES
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
     FL_STAMP(4);
     __hip_atomic_fetch_add(&sync[(blockIdx.x & (NCTR - 1)) * CTR_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     FL_STAMP(5);
@@ -531,10 +515,81 @@ __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, bo
   return *s_ok != 0;
 }
 
+// XCD-local arrival counters / registration counters inside `sync` (same pages as the device-wide ones)
+constexpr int LOC_OFF = 64;                             // sync[x * CTR_STRIDE + LOC_OFF]: arrivals of XCD x
+constexpr int REG_OFF = NCTR * CTR_STRIDE + 128;        // sync[REG_OFF + 32 * x]: blocks registered on XCD x
+
+// Barrier among the blocks of ONE XCD (LOCAL programs): rows of the batch never cross XCDs, so a phase only has to
+// wait for the blocks that share its L2. Plain stores + s_waitcnt vmcnt(0) put the data in that L2.
+constexpr int FL_LOCAL_SPREAD = 1;  // arrival counters per XCD (1, 4 measured: no difference)
+__device__ __forceinline__ bool xcd_barrier(unsigned* sync, int xcc, int slot, unsigned target, bool acquire, int* s_ok) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* ctr = &sync[xcc * CTR_STRIDE + LOC_OFF];
+    __hip_atomic_fetch_add(ctr + 64 * (slot % FL_LOCAL_SPREAD), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    int ok = 1;
+    for (;;) {
+      unsigned tot = 0;
+#pragma unroll
+      for (int q = 0; q < FL_LOCAL_SPREAD; ++q) tot += __hip_atomic_load(ctr + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tot >= target) break;
+      __builtin_amdgcn_s_sleep(1);
+      ++spins;
+      if ((spins & 255u) == 0 && (spins > SPIN_LIMIT || __hip_atomic_load(&sync[NCTR * CTR_STRIDE + 16], __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        __hip_atomic_store(&sync[NCTR * CTR_STRIDE + 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_ok = ok;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+// tiles a job contributes per 32-row tile of the batch
+__device__ __forceinline__ int tiles_per_rowtile(const fl_pjob& jb) {
+  switch (jb.kind) {
+    case FL_PJOB_GEMM: return jb.N / TS;
+    case FL_PJOB_ROWNORM: return TS / 4;
+    case FL_PJOB_SINUSOID: return (TS * (jb.N >> 1) + 255) / 256;
+    default: return (TS * (jb.N >> 2) + 255) / 256;  // GATHER, PSAMPLE: float4 per thread
+  }
+}
+
+template <bool WT>
+__device__ __forceinline__ void run_tile(const fl_pjob& jb, int rt, int k, const ProgIO& io, float* smem) {
+  const int r0 = rt * TS, r1 = r0 + TS < jb.M ? r0 + TS : jb.M;
+  switch (jb.kind) {
+    case FL_PJOB_GEMM: gemm_tile<WT>(jb, rt, k, io, smem); break;
+    case FL_PJOB_ROWNORM: rownorm_tile<WT>(jb, r0 + 4 * k, io); break;
+    case FL_PJOB_SINUSOID: sinusoid_tile<WT>(jb, r0, r1, k, io); break;
+    case FL_PJOB_GATHER: gather_tile<WT>(jb, r0, r1, k, io); break;
+    case FL_PJOB_PSAMPLE: psample_tile<WT>(jb, r0, r1, k, io); break;
+    default: break;
+  }
+}
+
+// LOCAL = false: every phase ends in a device-wide barrier, outputs are stored write-through, any block may run any tile.
+// LOCAL = true (opt-in; every job of the program works on the same batch rows, fl_program_run flag FL_PROG_XCD_LOCAL): the
+// 32-row tiles of the batch are dealt to the XCDs (row tile rt belongs to XCD rt % 8, the XCD being what the block READS
+// from HW_REG_XCC_ID, not an assumption about placement), a block only ever runs tiles of its own XCD's rows, data is
+// handed from phase to phase through that XCD's L2 (plain stores, loads that hit L2 instead of memory) and phases are
+// separated by a barrier among the ~32 blocks of the XCD. Every XCD streams all the weights (8 x the weight traffic,
+// out of the 256 MB Infinity Cache). Measured on the ConditionalUNet forward at batch 256 (tools/program_trace.py):
+// small-GEMM tiles drop from 5.6 to 1.9 us (operands arrive from the local L2), but the 1024-wide phases get slower
+// (12 vs 10.5 us: every XCD streams the whole 4 MB weight) and each block now decodes every job of a phase, so the
+// forward takes the same 0.25 ms as with device-wide barriers. Kept as an opt-in mode (FL_PROG_LOCAL=1), tested.
+template <bool LOCAL>
 __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __restrict__ phases, const fl_pjob* __restrict__ jobs,
                                                          int nphases, int njobs, const ProgIO io, unsigned* sync) {
+  constexpr bool WT = !LOCAL;  // (write-through stores in local mode too: measured, no difference)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ int s_ok;
+  __shared__ int s_ok, s_slot, s_nx;
   // the program lives in LDS for the whole run
   int* lprog = reinterpret_cast<int*>(smem + 2 * STAGE);
   {
@@ -559,6 +614,23 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
   constexpr int TB_OFF = offsetof(fl_pjob, tile_begin) / 4;
   const unsigned G = gridDim.x;
   bool alive = true;
+
+#if FL_PROG_TRACE
+  if (threadIdx.x == 0) g_trace = nullptr;  // the census barrier below runs before the first phase arms the trace
+#endif
+  int xcc = 0, slot = 0, nx = 1;
+  if constexpr (LOCAL) {
+    // which XCD am I on, and which of its blocks (a census, not an assumption); one device-wide barrier closes it
+    xcc = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))) & (NCTR - 1);  // HW_REG_XCC_ID[3:0]
+    if (threadIdx.x == 0)
+      s_slot = (int)__hip_atomic_fetch_add(&sync[REG_OFF + 32 * xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    alive = grid_barrier(sync, G, false, &s_ok);
+    if (threadIdx.x == 0) s_nx = (int)__hip_atomic_load(&sync[REG_OFF + 32 * xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    slot = __builtin_amdgcn_readfirstlane(s_slot);
+    nx = __builtin_amdgcn_readfirstlane(s_nx);
+  }
+
   for (int p = 0; p < nphases && alive; ++p) {
 #if FL_PROG_TRACE
     if (threadIdx.x == 0) {
@@ -574,21 +646,44 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
     const __attribute__((address_space(3))) int* ph = (const __attribute__((address_space(3))) int*)(lph + 4 * p);
     const int job_begin = __builtin_amdgcn_readfirstlane(ph[0]), job_end = __builtin_amdgcn_readfirstlane(ph[1]);
     const int ntiles = __builtin_amdgcn_readfirstlane(ph[2]);
-    for (int t = blockIdx.x; t < ntiles; t += G) {
-      int j = job_begin;
-      while (j + 1 < job_end &&
-             t >= __builtin_amdgcn_readfirstlane(((const __attribute__((address_space(3))) int*)ljb)[(j + 1) * JW + TB_OFF]))
-        ++j;
-      fl_pjob jb;
-      load_job(ljb + j * JW, jb);
-      const int lt = t - jb.tile_begin;
-      switch (jb.kind) {
-        case FL_PJOB_GEMM: gemm_tile(jb, lt, io, smem); break;
-        case FL_PJOB_ROWNORM: rownorm_tile(jb, lt, io); break;
-        case FL_PJOB_SINUSOID: sinusoid_tile(jb, lt, io); break;
-        case FL_PJOB_GATHER: gather_tile(jb, lt, io); break;
-        case FL_PJOB_PSAMPLE: psample_tile(jb, lt, io); break;
-        default: break;
+    if constexpr (!LOCAL) {
+      for (int t = blockIdx.x; t < ntiles; t += G) {
+        int j = job_begin;
+        while (j + 1 < job_end &&
+               t >= __builtin_amdgcn_readfirstlane(((const __attribute__((address_space(3))) int*)ljb)[(j + 1) * JW + TB_OFF]))
+          ++j;
+        fl_pjob jb;
+        load_job(ljb + j * JW, jb);
+        const int lt = t - jb.tile_begin;
+        const int nrt = (jb.M + TS - 1) / TS, per = tiles_per_rowtile(jb);
+        int rt, k;
+        if (jb.kind == FL_PJOB_GEMM && (per & 7) == 0) {
+          // tile lt runs on XCD lt%8 (round-robin block placement): keep a weight column block on one XCD
+          const int x = lt & 7, jj = lt >> 3, jc = jj / nrt;
+          k = x + 8 * jc;
+          rt = jj - jc * nrt;
+        } else {
+          rt = lt / per;
+          k = lt - rt * per;
+        }
+        run_tile<WT>(jb, rt, k, io, smem);
+      }
+    } else {
+      // my XCD's share of the phase: for every job, (its row tiles rt = xcc, xcc + 8, ...) x (tiles per row tile)
+      int base = 0;
+      for (int j = job_begin; j < job_end; ++j) {
+        fl_pjob jb;
+        load_job(ljb + j * JW, jb);
+        const int nrt = (jb.M + TS - 1) / TS, per = tiles_per_rowtile(jb);
+        const int mine = nrt > xcc ? (nrt - xcc + NCTR - 1) / NCTR : 0;
+        const int cnt = mine * per;
+        // local tile t of this job: first one this block takes is the smallest t >= 0 with (base + t) % nx == slot
+        int t = ((slot - base) % nx + nx) % nx;
+        for (; t < cnt; t += nx) {
+          const int rl = t / per, k = t - rl * per;
+          run_tile<WT>(jb, xcc + NCTR * rl, k, io, smem);
+        }
+        base += cnt;
       }
     }
     FL_STAMP(2);
@@ -600,17 +695,26 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
 #endif
     if (p + 1 < nphases) {
       const int next_flags = __builtin_amdgcn_readfirstlane(((const __attribute__((address_space(3))) int*)lph)[4 * (p + 1) + 3]);
-      alive = grid_barrier(sync, (unsigned)(p + 1) * G, (next_flags & FL_PPHASE_ACQUIRE) != 0, &s_ok);
+      const bool acq = (next_flags & FL_PPHASE_ACQUIRE) != 0;
+      if constexpr (LOCAL) alive = xcd_barrier(sync, xcc, slot, (unsigned)(p + 1) * (unsigned)nx, acq, &s_ok);
+      else alive = grid_barrier(sync, (unsigned)(p + 1) * G, acq, &s_ok);
     }
     FL_STAMP(6);
   }
   // self-cleaning: the last block to leave re-arms the counters for the next run (not after an abort)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0 && alive) {
     const unsigned old = __hip_atomic_fetch_add(&sync[NCTR * CTR_STRIDE], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (old == G - 1) {
 #pragma unroll
-      for (int g = 0; g < NCTR; ++g) __hip_atomic_store(&sync[g * CTR_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int g = 0; g < NCTR; ++g) {
+        __hip_atomic_store(&sync[g * CTR_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          __hip_atomic_store(&sync[g * CTR_STRIDE + LOC_OFF + 64 * q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sync[REG_OFF + 32 * g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __hip_atomic_store(&sync[NCTR * CTR_STRIDE], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       // every block has finished every phase: bump the per-run counters (step counter, Philox offset)
 #pragma unroll
@@ -664,18 +768,19 @@ int fl_program_job_tiles(const void* job) {
                  "program ROWNORM: N=%d lda=%d ldc=%d", j.N, j.lda[0], j.ldc);
       FL_REQUIRE(!j.W[1] || (j.bias[1] && j.aux[0]), "program ROWNORM: second norm needs bias[1] and aux[0]");
       FL_REQUIRE(!j.gate || (j.aux[1] && j.lda[1] % 4 == 0), "program ROWNORM: gate needs aux[1]");
-      return (j.M + 3) / 4;
+      return ((j.M + TS - 1) / TS) * (TS / 4);
     case FL_PJOB_SINUSOID:
       FL_REQUIRE(j.A[0] && j.W[0] && j.N % 2 == 0, "program SINUSOID: N=%d", j.N);
-      return (j.M * (j.N / 2) + 255) / 256;
+      return ((j.M + TS - 1) / TS) * ((TS * (j.N / 2) + 255) / 256);
     case FL_PJOB_GATHER:
       FL_REQUIRE(j.A[0] && j.W[0] && j.N % 4 == 0 && j.lda[0] % 4 == 0 && j.ldc % 4 == 0, "program GATHER: N=%d", j.N);
-      return (j.M * j.N / 4 + 255) / 256;
+      return ((j.M + TS - 1) / TS) * ((TS * (j.N / 4) + 255) / 256);
     case FL_PJOB_PSAMPLE:
       FL_REQUIRE(j.A[0] && j.A[1] && j.W[0] && j.W[1] && j.W[2] && j.aux[2] && (j.A[2] || j.aux[0]) &&
                      ((long long)j.M * j.N) % 4 == 0,
                  "program PSAMPLE: needs x, eps, alpha/alpha_bar/beta tables, t and noise or a Philox offset (M*N %% 4 == 0)");
-      return (int)(((long long)j.M * j.N / 4 + 255) / 256);
+      FL_REQUIRE(j.N % 4 == 0, "program PSAMPLE: N %% 4");
+      return ((j.M + TS - 1) / TS) * ((TS * (j.N / 4) + 255) / 256);
     default:
       fl::set_error("program job: unknown kind %d", j.kind);
       return FL_ERR_BAD_ARG;
@@ -685,7 +790,7 @@ int fl_program_job_tiles(const void* job) {
 int fl_program_sync_bytes(void) { return SYNC_UINTS * 4; }
 
 int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_jobs, const void* const* io, int n_io,
-                   void* sync, int max_blocks, const void* post, fl_stream_t stream) {
+                   void* sync, int max_blocks, int flags, const void* post, fl_stream_t stream) {
   FL_REQUIRE(phases && jobs && sync && n_phases >= 1 && n_jobs >= 1 && n_io >= 0 && n_io <= FL_PROG_MAX_IO && (n_io == 0 || io),
              "fl_program_run: bad args (n_phases=%d n_jobs=%d n_io=%d)", n_phases, n_jobs, n_io);
   FL_REQUIRE((size_t)n_phases * sizeof(fl_pphase) + (size_t)n_jobs * sizeof(fl_pjob) <= (size_t)PROG_LDS_BYTES,
@@ -704,14 +809,20 @@ int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_job
   }
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(program_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(program_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(program_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   });
   // the barrier needs every block resident: one block per CU (157 KB of LDS each: a second block cannot join it)
   int G = cus;
   if (max_blocks > 0 && max_blocks < G) G = max_blocks;
-  hipLaunchKernelGGL(program_kernel, dim3(G), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const fl_pphase*>(phases), reinterpret_cast<const fl_pjob*>(jobs), n_phases, n_jobs, pio,
-                     reinterpret_cast<unsigned*>(sync));
+  if (flags & FL_PROG_XCD_LOCAL)
+    hipLaunchKernelGGL(program_kernel<true>, dim3(G), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const fl_pphase*>(phases), reinterpret_cast<const fl_pjob*>(jobs), n_phases, n_jobs, pio,
+                       reinterpret_cast<unsigned*>(sync));
+  else
+    hipLaunchKernelGGL(program_kernel<false>, dim3(G), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const fl_pphase*>(phases), reinterpret_cast<const fl_pjob*>(jobs), n_phases, n_jobs, pio,
+                       reinterpret_cast<unsigned*>(sync));
   return fl::check_launch("program_kernel");
 }
 

@@ -40,6 +40,7 @@ def parse_header(path=HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"^[ \t]*#[^\n]*$", "", src, flags=re.M)  # preprocessor lines are not part of any prototype
     protos = {}
     for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(fl_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()

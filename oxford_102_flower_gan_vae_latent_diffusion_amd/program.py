@@ -13,7 +13,10 @@ import torch
 
 from . import lib, ops
 
+import os
+
 GEMM, ROWNORM, SINUSOID, GATHER, PSAMPLE = 0, 1, 2, 3, 4
+LOCAL_DEFAULT = os.environ.get("FL_PROG_LOCAL", "0") == "1"  # opt-in XCD-local execution (same speed, see program.hip)
 MAX_IO = 16
 
 JOB_DTYPE = np.dtype([
@@ -164,10 +167,16 @@ class ProgramBuilder:
                 jobs.append(j)
             ph[pi]["job_end"], ph[pi]["ntiles"] = len(jobs), t0
             max_tiles = max(max_tiles, t0)
+        # XCD-local execution (rows never cross XCDs) is legal when every job works on the same batch rows
+        ms = set(int(j["M"]) for j in jobs)
+        local_ok = len(ms) == 1
         jobs_np = np.stack(jobs)
         jobs_t = torch.from_numpy(np.frombuffer(jobs_np.tobytes(), dtype=np.uint8).copy()).to(device)
         ph_t = torch.from_numpy(np.frombuffer(ph.tobytes(), dtype=np.uint8).copy()).to(device)
-        return Program(ph_t, jobs_t, len(phases), len(jobs), max_tiles, self._keep, device)
+        prog = Program(ph_t, jobs_t, len(phases), len(jobs), max_tiles, self._keep, device)
+        prog.local_ok = local_ok
+        prog.local = local_ok and LOCAL_DEFAULT
+        return prog
 
 
 class Program:
@@ -176,6 +185,8 @@ class Program:
         self._keep = keep
         self.sync = torch.zeros(lib.load().fl_program_sync_bytes() // 4, dtype=torch.int32, device=device)
         self.max_blocks = 0  # 0 = one block per CU
+        self.local_ok = False  # every job works on the same batch rows: XCD-local execution is legal
+        self.local = False     # FL_PROG_XCD_LOCAL requested (only honoured by the builder when local_ok)
 
     def run(self, io, post=None):
         """io: list of tensors bound to the IO slots. Enqueues one kernel on the current stream (graph-capturable).
@@ -196,7 +207,7 @@ class Program:
             pbuf = ctypes.c_char_p(pp.tobytes())
         lib.call("fl_program_run", ctypes.c_void_p(self.phases.data_ptr()), ctypes.c_void_p(self.jobs.data_ptr()),
                  self.n_phases, self.n_jobs, arr, len(io), ctypes.c_void_p(self.sync.data_ptr()), self.max_blocks,
-                 pbuf, ops._stream())
+                 1 if self.local else 0, pbuf, ops._stream())
 
     def check(self):
         """Synchronising health check: raises if a barrier timed out (and re-arms the counters)."""

@@ -28,15 +28,16 @@ def test_tile_counts_and_phase_layout():
     a, w, c = torch.zeros(100, 64), torch.zeros(96, 64), torch.zeros(100, 96)
     x, g, b = torch.zeros(70, 512), torch.zeros(512), torch.zeros(512)
     pb.gemm(100, 96, [(a, 64, 64, w, 64)], c, 96)                      # ceil(100/32) * 96/32 = 12 tiles
-    pb.rownorm(70, 512, x, 512, g, b, 1e-5, torch.zeros(70, 512), 512)  # ceil(70/4) = 18 tiles
+    pb.rownorm(70, 512, x, 512, g, b, 1e-5, torch.zeros(70, 512), 512)  # 3 row tiles x 8 = 24 tiles
     pb.barrier()
-    pb.sinusoid(3, 256, torch.zeros(3, dtype=torch.int64), 1, torch.zeros(128), torch.zeros(3, 256), 256)  # 384/256 -> 2
-    pb.gather(5, 256, torch.zeros(10, 256), 256, torch.zeros(5, dtype=torch.int64), torch.zeros(5, 256), 256)  # 320/256 -> 2
+    pb.sinusoid(3, 256, torch.zeros(3, dtype=torch.int64), 1, torch.zeros(128), torch.zeros(3, 256), 256)  # 1 row tile x 16
+    pb.gather(40, 256, torch.zeros(10, 256), 256, torch.zeros(40, dtype=torch.int64), torch.zeros(40, 256), 256)  # 2 row tiles x 8
     prog = pb.finalize("cpu")
     ph, jb = phases_of(prog), jobs_of(prog)
-    assert [tuple(p)[:3] for p in ph] == [(0, 2, 30), (2, 4, 4)]
-    assert list(jb["ntiles"]) == [12, 18, 2, 2] and list(jb["tile_begin"]) == [0, 12, 0, 2]
-    assert prog.max_tiles == 30 and prog.n_jobs == 4
+    assert [tuple(p)[:3] for p in ph] == [(0, 2, 36), (2, 4, 32)]
+    assert list(jb["ntiles"]) == [12, 24, 16, 16] and list(jb["tile_begin"]) == [0, 12, 0, 16]
+    assert prog.max_tiles == 36 and prog.n_jobs == 4
+    assert not prog.local_ok and not prog.local  # jobs with different row counts: device-wide barriers only
 
 
 @pytest.mark.parametrize("bad", ["K", "lda", "N", "rownorm_D", "rownorm_second", "psample"])

@@ -225,3 +225,31 @@ def test_sampler_persistent_equals_multikernel(dev):
         d.rng.manual_seed(11)
         b = GraphSampler(d, (B, 256), dev, c, use_graph=True, persistent=False).run(x_T, n_steps=15, t_start=14).clone()
         close(a, b, 1e-4, "persistent vs multi-kernel sampler")
+
+
+def test_xcd_local_mode_is_stable(dev):
+    """Programs whose jobs all work on the same batch rows may run XCD-local (opt-in) (rows dealt to XCDs by an XCC_ID census, data
+    handed over through the XCD's L2 with plain stores, barriers among one XCD's blocks). A stale or mis-grouped
+    hand-off would show up as a wrong or varying result: 200 runs with fresh inputs against the multi-kernel engine,
+    ragged and multi-row-tile batches."""
+    un = _unet(dev, 7).eval()
+    for B in (256, 100, 512):
+        up = P.UNetProgram(un, B, dev)
+        assert up.prog.local_ok
+        up.prog.local = True
+        g = torch.Generator().manual_seed(B)
+        worst = 0.0
+        for it in range(200 if B == 256 else 40):
+            x = torch.randn(B, 256, generator=g).to(dev)
+            t = torch.randint(0, 1000, (B,), generator=g).to(dev)
+            c = torch.randint(0, 102, (B,), generator=g).to(dev)
+            with torch.no_grad():
+                out = up(x, t, c)
+                if it % 10 == 0:
+                    ref, _ = engine.unet_forward(un, x, t, c)
+                    err = (out - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+                    worst = max(worst, err)
+        up.prog.check()
+        assert worst <= 3e-5, "B=%d: XCD-local forward deviates (%.3e)" % (B, worst)
+    # the shared-timestep program has M=1 jobs: it must fall back to device-wide barriers
+    assert not P.UNetProgram(un, 64, dev, shared_t=True, has_class=False).prog.local_ok

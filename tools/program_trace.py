@@ -64,3 +64,14 @@ for p in range(nph):
     cyc = trace.view(G, nph, 12)[act, p, 11].double().cpu()
     mhz = (cyc / (tiles_done[act] - s[act])).mean()
     print("%-5d %8.2f %8.2f | %8.2f %8.2f %8.2f %8.2f %8.2f | %d tiles%s  clk %.0f MHz" % (p, start, end - start, tile_t, mf, fence, atom, spin, ntiles, det, mhz))
+
+# per-block phase durations (phase start -> next phase start): meaningful in XCD-local mode too, where the XCDs drift
+print("\nper-block phase duration (start -> next start), mean / max over blocks; tile time = mean over blocks that ran a tile")
+tot = 0.0
+for p in range(nph - 1):
+    d = tr[:, p + 1, 0] - tr[:, p, 0]
+    ran = tr[:, p, 2] - tr[:, p, 0]
+    tile = ran[ran > 0.3].mean() if (ran > 0.3).any() else float("nan")
+    tot += d.mean()
+    print("%-3d %7.2f %7.2f   tiles %6.2f  (%d tiles)" % (p, d.mean(), d.max(), tile, int(jobs_per_phase[p, 2])))
+print("sum of mean phase durations %.1f us; launch span %.1f us" % (tot, tr[:, nph - 1, 2].max() - tr[:, 0, 0].min()))
