@@ -294,6 +294,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   __syncthreads();
   if (rl == 0 && c < N) partial[(long long)blockIdx.y * N + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
+// short matrices (M <= 1024: the denoiser's bias gradients, M = batch): the whole reduction in ONE launch
+__global__ __launch_bounds__(1024) void colsum_small_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N,
+                                                             long long ldx, float alpha, float beta) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a = 0.f;
+  if (c < N)
+    for (int r = rl; r < M; r += 16) a += x[(long long)r * ldx + c];
+  red[rl][cl] = a;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) a += red[k][cl];
+    out[c] = beta != 0.f ? beta * out[c] + alpha * a : alpha * a;
+  }
+}
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                              int slabs, int N, float alpha, float beta) {
   __shared__ float red[16][64];
@@ -460,6 +477,10 @@ int fl_colsum(const float* x, int64_t ldx, float* out, int M, int N, float alpha
               fl_stream_t stream) {
   FL_REQUIRE(ws && ws_bytes >= fl_colsum_workspace_bytes(M, N), "fl_colsum: workspace too small");
   if (!N) return FL_OK;
+  if (M <= 1024) {
+    hipLaunchKernelGGL(colsum_small_kernel, dim3(fl::cdiv(N, 64)), dim3(1024), 0, ST(stream), x, out, M, N, (long long)ldx, alpha, beta);
+    return fl::check_launch("colsum_small");
+  }
   const int rps = colsum_rps(M), slabs = fl::cdiv(M, rps);
   float* partial = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(fl::cdiv(N, 64), slabs > 0 ? slabs : 1), dim3(256), 0, ST(stream), x, partial, M, N, (long long)ldx, rps);
