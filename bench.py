@@ -78,6 +78,23 @@ def measure_dominant_kernel(dev, B, reps=5):
     return dict(avg_ms=tot_t / n, tflops=tot_f / tot_t / 1e9, flop_per_launch=tot_f / n, launches=n, per=per)
 
 
+def split_vs_fp32_mfma(dev):
+    """In-run evidence for the default GEMM math: the same convolution (res2.conv shape at batch 32, K = 2304) through
+    the exact-bf16-split path and through the native fp32 MFMA -> max |difference| relative to max |output|."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
+    old = ops.get_gemm_math()
+    x = torch.empty(32, 16, 16, 256, device=dev)
+    ops.philox_fill(x, seed=21, mode=0)
+    w = torch.empty(256, 3, 3, 256, device=dev)
+    ops.philox_fill(w, seed=22, mode=0)
+    outs = {}
+    for mode in ("fp32", "split"):
+        ops.set_gemm_math(mode)
+        outs[mode] = ops.conv2d_fwd(x, w, None, 1, 1)
+    ops.set_gemm_math(old)
+    return float((outs["split"] - outs["fp32"]).abs().max() / outs["fp32"].abs().max())
+
+
 def cpu_baseline(threads, B=32, iters=6):
     """The CPU oracle (validated restatement of the reference's step, same torch-CPU ops) timed on this box's
     host cores on a bounded sample of the same workload. Checker code: imported only here."""
@@ -267,6 +284,7 @@ def main():
                 "peak_basis": ("bf16 dense MFMA peak %.0f / %d piece products per fp32 product" % (BF16_MFMA_PEAK_TFLOPS, SPLIT_PIECE_PRODUCTS))
                               if split else "fp32 dense MFMA peak",
                 "achieved_over_fp32_mfma_peak": r["tflops"] / FP32_MFMA_PEAK_TFLOPS,
+                "split_vs_fp32_mfma_max_rel_diff": split_vs_fp32_mfma(dev),
                 # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, averaged over the 9
                 # launches at B=256; profiles/r01_conv_kernel_pmc.md). Not re-measured live: PMC needs the profiler.
                 "traffic": (4.4e8 if split else 4.08e8) if B == 256 else None,
