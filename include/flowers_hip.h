@@ -239,7 +239,9 @@ int fl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const 
 int fl_kl_fwd(const float* mu, const float* logvar, float* kl_row, float* musq_row, float* loss, int B, int D,
               fl_stream_t stream);                                                                    /* v2:380-386 */
 int fl_kl_bwd(const float* mu, const float* logvar, const float* kl_row, float gscale, const float* gdev, float* dmu,
-              float* dlv, int B, int D, fl_stream_t stream);
+              float* dlv, int B, int D, float reg_scale, fl_stream_t stream);
+/* reg_scale multiplies the gradient of the batch-SUM term 1e-4*sum(mu^2) (v2:385): 1 on one GPU; the world size in a
+ * data-parallel step, where shard gradients are averaged although that term adds up over the global batch */
 int fl_bce_fwd(const float* p, float target, float* loss, int n, fl_stream_t stream);                /* v2:1029 */
 int fl_bce_bwd(const float* p, float target, float gscale, const float* gdev, float* dp, int n, fl_stream_t stream);
 int fl_cross_entropy_fwd(const float* logits, const int64_t* labels, float* row_loss, float* probs, float* loss, int B,

@@ -134,7 +134,7 @@ __global__ void kl_final_kernel(const float* kl_row, const float* musq_row, floa
 }
 __global__ void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
                               const float* __restrict__ kl_row, float gscale, const float* __restrict__ gdev,
-                              float* __restrict__ dmu, float* __restrict__ dlv, int B, int D) {
+                              float* __restrict__ dmu, float* __restrict__ dlv, int B, int D, float reg_scale) {
   const float g = gscale * (gdev ? gdev[0] : 1.f);
   const long long n = (long long)B * D;
   GRID_STRIDE(i, n) {
@@ -144,7 +144,7 @@ __global__ void kl_bwd_kernel(const float* __restrict__ mu, const float* __restr
     const float m = fminf(fmaxf(mr, -10.f), 10.f), lv = fminf(fmaxf(lr, -2.f), 10.f);
     const float k = kl_row[b];
     const float gate = (k >= 0.f && k <= 100.f) ? 1.f : 0.f;  // clamp passes gradient inside [min,max]
-    const float gm = (gate * (1.f / B) * m + 2e-4f * m) * (m_in ? 1.f : 0.f);
+    const float gm = (gate * (1.f / B) * m + reg_scale * 2e-4f * m) * (m_in ? 1.f : 0.f);
     const float gl = gate * (1.f / B) * (-0.5f) * (1.f - expf(lv)) * (l_in ? 1.f : 0.f);
     dmu[i] = g * gm;
     dlv[i] = g * gl;
@@ -323,10 +323,10 @@ int fl_kl_fwd(const float* mu, const float* logvar, float* kl_row, float* musq_r
   return fl::check_launch("kl_fwd");
 }
 int fl_kl_bwd(const float* mu, const float* logvar, const float* kl_row, float gscale, const float* gdev, float* dmu,
-              float* dlv, int B, int D, fl_stream_t stream) {
+              float* dlv, int B, int D, float reg_scale, fl_stream_t stream) {
   const long long n = (long long)B * D;
   if (!n) return FL_OK;
-  hipLaunchKernelGGL(kl_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), mu, logvar, kl_row, gscale, gdev, dmu, dlv, B, D);
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), mu, logvar, kl_row, gscale, gdev, dmu, dlv, B, D, reg_scale);
   return fl::check_launch("kl_bwd");
 }
 int fl_bce_fwd(const float* p, float target, float* loss, int n, fl_stream_t stream) {

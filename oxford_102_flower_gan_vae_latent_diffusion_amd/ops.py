@@ -603,20 +603,22 @@ def adam_step(p, g, m, v, lr_dev, step_dev, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, 
               float(eps), float(wd), _p(coef_dev), float(gscale), int(decoupled), _stream())
 
 
-def kl_fwd(mu, logvar):
+def kl_fwd(mu, logvar, want_musq=False):
+    """-> (loss, kl_row[, musq_row]): loss = mean(clamp(kl_row, 0, 100)) + 1e-4 * sum(musq_row)  (v2:380-386)."""
     _chk(mu, logvar)
     B, D = mu.shape
     kl_row, musq = new((B,), mu), new((B,), mu)
     loss = new((1,), mu)
     _lib.call("fl_kl_fwd", _p(mu), _p(logvar), _p(kl_row), _p(musq), _p(loss), B, D, _stream())
-    return loss, kl_row
+    return (loss, kl_row, musq) if want_musq else (loss, kl_row)
 
 
-def kl_bwd(mu, logvar, kl_row, gscale=1.0, gdev=None):
+def kl_bwd(mu, logvar, kl_row, gscale=1.0, gdev=None, reg_scale=1.0):
     _chk(mu, logvar, kl_row, gdev)
     B, D = mu.shape
     dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
-    _lib.call("fl_kl_bwd", _p(mu), _p(logvar), _p(kl_row), float(gscale), _p(gdev), _p(dmu), _p(dlv), B, D, _stream())
+    _lib.call("fl_kl_bwd", _p(mu), _p(logvar), _p(kl_row), float(gscale), _p(gdev), _p(dmu), _p(dlv), B, D,
+              float(reg_scale), _stream())
     return dmu, dlv
 
 

@@ -298,11 +298,25 @@ def kl_weight_at(epoch, num_epochs, start=0.001, end=0.05):
 
 
 class VAEGANTrainer:
-    """VAE-GAN training step (configs 1/2 of BASELINE.json), v2:1060-1134."""
+    """VAE-GAN training step (configs 1/2 of BASELINE.json), v2:1060-1134.
+
+    Data parallel (world_size > 1; one process per GPU, each with a shard of the batch): the step is the
+    GLOBAL-batch step of the reference for everything except BatchNorm -
+      * the gradients of the autoencoder and of the discriminator are all-reduced (flat buffers, two collectives) and
+        averaged inside the Adam kernels;
+      * the six loss terms that drive the balancing coefficients (v2:1107-1125) are all-reduced first, so every rank uses
+        the coefficients of the global batch; the KL term is the mean over the batch PLUS a batch sum 1e-4*sum(mu^2)
+        (v2:385): the mean part is averaged, the sum part added over ranks, and its gradient scaled by world_size
+        (shard gradients are averaged afterwards);
+      * the class-centre EMA (v2:369-378) runs on the all-gathered latents and labels, identically on every rank;
+      * Discriminator64's BatchNorm uses the LOCAL shard statistics (what torch DDP does without SyncBatchNorm): the
+        adversarial gradients therefore differ from a single-process run on the global batch; everything else is exact.
+    Collectives are eager torch.distributed calls (RCCL on GPUs), so the data-parallel step is not graph-captured."""
 
     def __init__(self, autoencoder, discriminator, vgg, lr=1e-4, lambda_cls=0.1, lambda_center=0.05, lambda_vgg=0.4,
-                 lambda_gan=0.2):
+                 lambda_gan=0.2, process_group=None, world_size=1):
         self.ae, self.disc, self.vgg = autoencoder, discriminator, vgg
+        self.pg, self.world = process_group, int(world_size)
         dev = next(autoencoder.parameters()).device
         self.dev = dev
         self.fp = FlatParams(autoencoder, ("classifier.",))
@@ -318,6 +332,8 @@ class VAEGANTrainer:
     def capture(self, data, labels, epoch=0, num_epochs=300):
         """Capture the whole step (one loss phase = one graph) as a hipGraph; `data`/`labels` become the static input
         buffers. replay() after copying a new batch into them."""
+        if self.world > 1:
+            raise RuntimeError("the data-parallel VAE-GAN step issues eager collectives: call step(), not capture()")
         self.static_data, self.static_labels = data, labels
         for _ in range(2):
             self.step(data, labels, epoch=epoch, num_epochs=num_epochs)
@@ -353,7 +369,12 @@ class VAEGANTrainer:
         fy, _ = engine_bwd.vgg_features(vgg, data, False)
         percep, pn = ops.euclid_loss_fwd(fx, fy)
         zero = torch.zeros(1, dtype=torch.float32, device=self.dev)
-        kl, kl_row = ops.kl_fwd(mu, logvar) if klf > 0 else (zero, None)
+        W = self.world
+        musq = None
+        if klf > 0:
+            kl, kl_row, musq = ops.kl_fwd(mu, logvar, want_musq=True)
+        else:
+            kl, kl_row = zero, None
         if clsf > 0:
             m1, m2 = cls_masks
             if ae.training and m1 is None:
@@ -378,11 +399,24 @@ class VAEGANTrainer:
         Gf, _ = engine_bwd.disc_bwd(D, S_f, ops.bce_bwd(p_fake, 0.0, 0.5), need_wgrad=True, need_dx=False)
         self.dfp.set_grads(Gr)
         self.dfp.add_grads(Gf)
-        self.d_opt.step()
+        allreduce_grads(self.dfp, W, self.pg)
+        self.d_opt.step(gscale=1.0 / W)
         # ---- generator adversarial term with the UPDATED discriminator (v2:1105) ----
         p_adv, S_a = engine_bwd.disc_fwd(D, recon)
         adv = ops.bce_fwd(p_adv, 1.0)
         # ---- device-side loss balancing (v2:1107-1125) ----
+        if W > 1:
+            import torch.distributed as dist
+            # [recon, percep, kl mean part, adv, ce, centre | kl batch-sum part]: means are averaged, the sum is summed
+            tv = torch.zeros(8, dtype=torch.float32, device=self.dev)
+            reg = ops.colsum(musq.view(B, 1), alpha=1e-4) if musq is not None else zero
+            klmean = ops.axpby(1.0, kl, -1.0, reg) if musq is not None else zero
+            for i, tsr in enumerate((recon_loss, percep, klmean, adv, ce, cen)):
+                ops.axpby(1.0 / W, tsr, out=tv[i:i + 1])
+            ops.axpby(1.0, reg, out=tv[6:7])
+            dist.all_reduce(tv, group=self.pg)
+            recon_loss, percep, adv, ce, cen = tv[0:1], tv[1:2], tv[3:4], tv[4:5], tv[5:6]
+            kl = ops.axpby(1.0, tv[2:3], 1.0, tv[6:7])
         for i, tsr in enumerate((recon_loss, percep, kl, adv, ce, cen)):
             ops.axpby(1.0, tsr, out=self.terms[i:i + 1])
         wkey = (1.0, l_vgg, klw * klf, l_gan, l_cls * clsf, l_cen * cenf)
@@ -408,14 +442,27 @@ class VAEGANTrainer:
             dz = engine_bwd._add(dz, ops.euclid_loss_bwd(z, cb, cn, 1.0, coeff[5:6]))
         dmu, dlv = dz, ops.reparam_bwd(dz, logvar, reparam_eps)
         if klf > 0:
-            dmu_k, dlv_k = ops.kl_bwd(mu, logvar, kl_row, 1.0, coeff[2:3])
+            dmu_k, dlv_k = ops.kl_bwd(mu, logvar, kl_row, 1.0, coeff[2:3], reg_scale=float(W))
             dmu, dlv = engine_bwd._add(dmu, dmu_k), engine_bwd._add(dlv, dlv_k)
         G_enc, _ = engine_bwd.encoder_bwd(ae.encoder, S_enc, dmu, dlv)
         self.fp.set_grads(G_enc, "encoder.")
         self.fp.set_grads(G_dec, "decoder.")
-        self.opt.step(n=n_act)                                   # clip 1.0 + AdamW (v2:1128-1129)
+        if W > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.fp.grad[:n_act], group=self.pg)
+        self.opt.step(gscale=1.0 / W, n=n_act)                   # clip 1.0 + AdamW (v2:1128-1129)
         if epoch >= 60 and cenf > 0:                             # v2:1132-1134
-            ops.update_centers(ae.class_centers, z, labels, 0.9)
+            zc, lc = z, labels
+            if W > 1:  # every rank applies the EMA of the global batch: gather (sum of disjoint slices: any backend)
+                import torch.distributed as dist
+                r = dist.get_rank(self.pg)
+                zc = torch.zeros(W * B, z.shape[1], dtype=torch.float32, device=self.dev)
+                lc = torch.zeros(W * B, dtype=torch.int64, device=self.dev)
+                zc[r * B:(r + 1) * B].copy_(z)
+                lc[r * B:(r + 1) * B].copy_(labels)
+                dist.all_reduce(zc, group=self.pg)
+                dist.all_reduce(lc, group=self.pg)
+            ops.update_centers(ae.class_centers, zc, lc, 0.9)
         self.out = dict(total=total, recon=recon_loss, perceptual=percep, kl=kl, cls=ce, center=cen, adv=adv,
                         d_loss=d_loss, recon_x=recon, mu=mu, logvar=logvar, z=z, grad_norm=self.opt.grad_norm)
         return self.out

@@ -76,3 +76,31 @@ def test_flat_allreduce_equals_global_batch_gradient():
     assert len(ret) == world
     for r, w in ret.items():
         assert w < 1e-4, (r, w)
+
+
+def test_kl_term_data_parallel_rule():
+    """The KL term of v2:380-386 is mean(clamped kl rows) + 1e-4 * SUM(mu^2): in a data-parallel VAE-GAN step the mean part
+    is averaged over ranks, the sum part is added, and its shard gradient is scaled by the world size before the
+    gradients are averaged (steps.VAEGANTrainer, fl_kl_bwd reg_scale). Checked here with the oracle on CPU."""
+    from oracle import v2_oracle as O
+    g = torch.Generator().manual_seed(5)
+    B, W = 8, 2
+    mu = (torch.randn(B, 16, generator=g) * 3).double().requires_grad_(True)
+    lv = torch.randn(B, 16, generator=g).double().requires_grad_(True)
+    full = O.kl_divergence(mu, lv)
+    full.backward()
+    g_mu, g_lv = mu.grad.clone(), lv.grad.clone()
+    per = B // W
+    mean_parts, reg_parts, gm, gl = [], [], torch.zeros_like(g_mu), torch.zeros_like(g_lv)
+    for r in range(W):
+        m = mu.detach()[r * per:(r + 1) * per].clone().requires_grad_(True)
+        l = lv.detach()[r * per:(r + 1) * per].clone().requires_grad_(True)
+        reg = 1e-4 * torch.clamp(m, -10, 10).pow(2).sum()
+        mean_part = O.kl_divergence(m, l) - reg
+        (mean_part + W * reg).backward()            # shard loss whose AVERAGED gradient is the global one
+        mean_parts.append(mean_part.detach())
+        reg_parts.append(reg.detach())
+        gm[r * per:(r + 1) * per] = m.grad / W
+        gl[r * per:(r + 1) * per] = l.grad / W
+    assert abs(float(sum(mean_parts) / W + sum(reg_parts) - full.detach())) < 1e-12
+    assert float((gm - g_mu).abs().max()) < 1e-12 and float((gl - g_lv).abs().max()) < 1e-12
