@@ -1,5 +1,6 @@
+"""RGB stem conv (3->64, 3x3) through fl_conv2d_fwd / fl_conv2d_fwd_instnorm at batch 256, next to the write floor."""
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
 dev = torch.device("cuda:0")
 B = 256
