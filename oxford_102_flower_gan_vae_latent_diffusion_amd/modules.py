@@ -472,6 +472,9 @@ class ConditionalUNet(nn.Module):
                 cache.clear()
             up = UNetProgram(self, B, x.device, shared_t=shared_t, has_class=c is not None, masks=block_masks is not None)
             cache[key] = up
+        self._pcalls = getattr(self, "_pcalls", 0) + 1
+        if self._pcalls % 256 == 0 and not torch.cuda.is_current_stream_capturing():
+            up.prog.check()  # amortised health check (one sync per 256 forwards): a timed-out barrier raises here
         return up(x, t.contiguous(), c.contiguous() if c is not None else None, block_masks, head_masks)
 
 
