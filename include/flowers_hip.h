@@ -156,6 +156,21 @@ int fl_groupnorm_bwd(const float* dy, const float* x, const float* scale, const 
 int fl_batchnorm_bwd(const float* dy, const float* x, const float* scale, const float* shift, const float* w,
                      const float* mean, const float* rstd, int act, float act_param, float* dx, float* dw, float* db,
                      float* coef, int B, int HW, int C, void* ws, size_t ws_bytes, fl_stream_t stream);
+/* Synchronised batch norm for the data-parallel VAE-GAN step (the reference's nn.BatchNorm2d layers of
+ * Discriminator64, v2:591-603, under torch's SyncBatchNorm rule): the per-channel reductions are split where
+ * ranks exchange them. sums = double[2*C]: {sum x, sum x^2} (dy NULL) or {sum g, sum g*x}, g = dy*act'(norm(x)).
+ * The caller all-reduces `sums` (SUM) and finishes with the *_from_sums call, n_total = world * B * HW.
+ * dx uses the global sums, dw/db this rank's local ones. coef is scratch: 8*C floats. */
+int fl_batchnorm_sums(const float* x, const float* dy, const float* scale, const float* shift, int act,
+                      float act_param, double* sums, int B, int HW, int C, void* ws, size_t ws_bytes,
+                      fl_stream_t stream);
+int fl_batchnorm_stats_from_sums(const double* sums, int64_t n_total, const float* w, const float* b, float eps,
+                                 float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                                 float* mean, float* rstd, int C, fl_stream_t stream);
+int fl_batchnorm_bwd_from_sums(const float* dy, const float* x, const float* scale, const float* shift, const float* w,
+                               const float* mean, const float* rstd, int act, float act_param,
+                               const double* sums_global, const double* sums_local, int64_t n_total, float* dx,
+                               float* dw, float* db, float* coef, int B, int HW, int C, fl_stream_t stream);
 /* per-image channel sums: out1[b,c] = sum_pix a, out2[b,c] = sum_pix a*x, a = dy (or x if dy NULL) — v2:56,65 */
 int fl_chan_sums(const float* x, const float* dy, float* out1, float* out2, int B, int HW, int C, void* ws,
                  size_t ws_bytes, fl_stream_t stream);

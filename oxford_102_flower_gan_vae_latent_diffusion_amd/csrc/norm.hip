@@ -593,6 +593,50 @@ int fl_batchnorm_bwd(const float* dy, const float* x, const float* scale, const 
   return fl::check_launch("fl_batchnorm_bwd");
 }
 
+/* ---- data-parallel (synchronised) batch norm: the two reductions are split at the point where
+ * ranks exchange their per-channel sums (2C doubles), so the statistics are those of the global
+ * batch as torch's SyncBatchNorm computes them. */
+int fl_batchnorm_sums(const float* x, const float* dy, const float* scale, const float* shift, int act,
+                      float act_param, double* sums, int B, int HW, int C, void* ws, size_t ws_bytes,
+                      fl_stream_t stream) {
+  NORM_CHECKS("fl_batchnorm_sums");
+  FL_REQUIRE(x && sums, "fl_batchnorm_sums: null argument");
+  FL_REQUIRE(!dy || (scale && shift), "fl_batchnorm_sums: backward sums need scale/shift");
+  int rc = dy ? run_partial(1, x, dy, scale, shift, 0, act, act_param, partial, B, HW, C, sl, st)
+              : run_partial(0, x, nullptr, nullptr, nullptr, 0, 0, 0.f, partial, B, HW, C, sl, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(collapse_rows, dim3(fl::cdiv(2 * C, 64), 1), dim3(1024), 0, st, partial, sums, B * sl.S, 2 * C);
+  return fl::check_launch("fl_batchnorm_sums");
+}
+
+int fl_batchnorm_stats_from_sums(const double* sums, int64_t n_total, const float* w, const float* b, float eps,
+                                 float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                                 float* mean, float* rstd, int C, fl_stream_t stream) {
+  FL_REQUIRE(sums && w && b && scale && shift, "fl_batchnorm_stats_from_sums: null argument");
+  FL_REQUIRE(n_total > 0 && n_total < (1ll << 31), "fl_batchnorm_stats_from_sums: n_total=%lld out of range", (long long)n_total);
+  hipLaunchKernelGGL(bnorm_finalize_fwd<double>, dim3(fl::cdiv(C, 128)), dim3(128), 0, reinterpret_cast<hipStream_t>(stream),
+                     sums, w, b, eps, momentum, running_mean, running_var, 1, scale, shift, mean, rstd, 1, (int)n_total, C, 1, 1);
+  return fl::check_launch("fl_batchnorm_stats_from_sums");
+}
+
+int fl_batchnorm_bwd_from_sums(const float* dy, const float* x, const float* scale, const float* shift, const float* w,
+                               const float* mean, const float* rstd, int act, float act_param,
+                               const double* sums_global, const double* sums_local, int64_t n_total, float* dx,
+                               float* dw, float* db, float* coef /*8*C*/, int B, int HW, int C, fl_stream_t stream) {
+  FL_REQUIRE(C % 4 == 0 && dy && x && scale && shift && w && mean && rstd && sums_global && sums_local && dx && dw && db && coef,
+             "fl_batchnorm_bwd_from_sums: bad args (C=%d)", C);
+  FL_REQUIRE(n_total > 0 && n_total < (1ll << 31), "fl_batchnorm_bwd_from_sums: n_total=%lld out of range", (long long)n_total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float *A = coef, *Bc = coef + C, *Cc = coef + 2 * (size_t)C, *t0 = coef + 3 * (size_t)C;
+  // dx coefficients from the global sums; dw/db (this rank's share, all-reduced with the other gradients) from the local ones
+  hipLaunchKernelGGL(bnorm_finalize_bwd<double>, dim3(fl::cdiv(C, 128)), dim3(128), 0, st, sums_global, w, mean, rstd, A, Bc, Cc, t0, t0 + C, 1, (int)n_total, C, 1, 1);
+  hipLaunchKernelGGL(bnorm_finalize_bwd<double>, dim3(fl::cdiv(C, 128)), dim3(128), 0, st, sums_local, w, mean, rstd, t0, t0 + C, t0 + 2 * (size_t)C, dw, db, 1, (int)n_total, C, 1, 1);
+  const long long total4 = (long long)B * HW * (C / 4);
+  if (total4 == 0) return FL_OK;
+  hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, st, dy, x, scale, shift, A, Bc, Cc, 0, dx, total4, HW, C / 4, act, act_param);
+  return fl::check_launch("fl_batchnorm_bwd_from_sums");
+}
+
 int fl_layernorm_fwd(const float* x, const float* w, const float* b, const float* mask, const float* R, float* y,
                      float* mean, float* rstd, int rows, int D, float eps, int act, float act_param, fl_stream_t stream) {
   FL_REQUIRE(x && w && b && y && D % 4 == 0, "fl_layernorm_fwd: bad args (D=%d)", D);

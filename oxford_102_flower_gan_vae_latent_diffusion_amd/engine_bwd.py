@@ -392,9 +392,10 @@ class VGGLossFn(torch.autograd.Function):
 
 
 # ============================================================================= Discriminator64 (v2:983-1007)
-def disc_fwd(dm, x, save=True):
+def disc_fwd(dm, x, save=True, sync=None, world=1):
     """x NCHW (B,3,64,64) -> probabilities (B,). BatchNorm uses batch statistics when dm.training (and updates the
-    running buffers exactly like nn.BatchNorm2d), running statistics otherwise."""
+    running buffers exactly like nn.BatchNorm2d), running statistics otherwise. sync/world: the data-parallel step's
+    all-reduce hook (ops.batchnorm_stats) -> statistics of the global batch; disc_bwd reuses it from the tape."""
     pk = dm._pk
     m = dm.model
     S = RBSaved()
@@ -402,12 +403,13 @@ def disc_fwd(dm, x, save=True):
     S.y0 = ops.conv2d_fwd(S.x4, pk.conv(m[0]), _d(m[0].bias), 2, 1, act=LRELU, act_param=0.2)
     h = S.y0
     S.blocks = []
+    S.sync, S.world = (sync if dm.training else None), world
     for ci, bi in ((2, 3), (5, 6), (8, 9)):
         conv, bn = m[ci], m[bi]
         hin = h
         yc = ops.conv2d_fwd(hin, pk.conv(conv), _d(conv.bias), 2, 1)
         nb = ops.batchnorm_stats(yc, _d(bn.weight), _d(bn.bias), bn.running_mean, bn.running_var, dm.training,
-                                 bn.momentum, bn.eps)
+                                 bn.momentum, bn.eps, sync=sync, world=world)
         if dm.training:
             bn.num_batches_tracked += 1
         h = ops.affine_act(yc, nb[0], nb[1], act=LRELU, act_param=0.2)
@@ -431,7 +433,8 @@ def disc_bwd(dm, S, dp, need_wgrad=True, need_dx=True):
     dh = ops.linear_dgrad(dlogit, S.wf).view(-1, 4, 4, 512)
     for (ci, bi), (hin, yc, nb) in zip(((8, 9), (5, 6), (2, 3)), reversed(S.blocks)):
         conv, bn = m[ci], m[bi]
-        dyc, dw, db = ops.batchnorm_bwd(dh, yc, nb[0], nb[1], _d(bn.weight), nb[2], nb[3], act=LRELU, act_param=0.2)
+        dyc, dw, db = ops.batchnorm_bwd(dh, yc, nb[0], nb[1], _d(bn.weight), nb[2], nb[3], act=LRELU, act_param=0.2,
+                                        sync=S.sync, world=S.world)
         if need_wgrad:
             Co, Cin = conv.weight.shape[0], conv.weight.shape[1]
             G["model.%d.weight" % bi], G["model.%d.bias" % bi] = dw, db

@@ -303,11 +303,20 @@ def groupnorm_stats(x, w, b, G, eps=1e-5):
     return scale, shift, mean, rstd
 
 
-def batchnorm_stats(x, w, b, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+def batchnorm_stats(x, w, b, running_mean, running_var, training, momentum=0.1, eps=1e-5, sync=None, world=1):
+    """sync: callable all-reducing (SUM) a float64 tensor in place across `world` ranks -> statistics of
+    the global batch (SyncBatchNorm rule); None -> this rank's batch only."""
     _chk(x, w, b, running_mean, running_var)
     B, H, W, C = x.shape
     scale, shift, mean, rstd = (new((C,), x) for _ in range(4))
     wsp, wsn = _norm_ws(B, H * W, C, x)
+    if sync is not None and training:
+        sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+        _lib.call("fl_batchnorm_sums", _p(x), None, None, None, 0, 0.0, _p(sums), B, H * W, C, wsp, wsn, _stream())
+        sync(sums)
+        _lib.call("fl_batchnorm_stats_from_sums", _p(sums), int(world) * B * H * W, _p(w), _p(b), float(eps), float(momentum),
+                  _p(running_mean), _p(running_var), _p(scale), _p(shift), _p(mean), _p(rstd), C, _stream())
+        return scale, shift, mean, rstd
     _lib.call("fl_batchnorm_stats", _p(x), _p(w), _p(b), float(eps), float(momentum), _p(running_mean),
               _p(running_var), int(training), _p(scale), _p(shift), _p(mean), _p(rstd), B, H * W, C, wsp, wsn, _stream())
     return scale, shift, mean, rstd
@@ -349,13 +358,25 @@ def groupnorm_bwd(dy, x, scale, shift, w, mean, rstd, G, act=ACT_NONE, act_param
     return dx, dw, db
 
 
-def batchnorm_bwd(dy, x, scale, shift, w, mean, rstd, act=ACT_NONE, act_param=0.0):
+def batchnorm_bwd(dy, x, scale, shift, w, mean, rstd, act=ACT_NONE, act_param=0.0, sync=None, world=1):
+    """sync/world as in batchnorm_stats: dx from the global-batch sums, dw/db this rank's share."""
     _chk(dy, x, scale, shift, w, mean, rstd)
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
     dw, db = new((C,), x), new((C,), x)
-    coef = new((3, C), x)
     wsp, wsn = _norm_ws(B, H * W, C, x)
+    if sync is not None:
+        local = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+        _lib.call("fl_batchnorm_sums", _p(x), _p(dy), _p(scale), _p(shift), act, float(act_param), _p(local), B, H * W, C,
+                  wsp, wsn, _stream())
+        glob = local.clone()
+        sync(glob)
+        coef = new((8, C), x)
+        _lib.call("fl_batchnorm_bwd_from_sums", _p(dy), _p(x), _p(scale), _p(shift), _p(w), _p(mean), _p(rstd), act,
+                  float(act_param), _p(glob), _p(local), int(world) * B * H * W, _p(dx), _p(dw), _p(db), _p(coef), B, H * W, C,
+                  _stream())
+        return dx, dw, db
+    coef = new((3, C), x)
     _lib.call("fl_batchnorm_bwd", _p(dy), _p(x), _p(scale), _p(shift), _p(w), _p(mean), _p(rstd), act,
               float(act_param), _p(dx), _p(dw), _p(db), _p(coef), B, H * W, C, wsp, wsn, _stream())
     return dx, dw, db

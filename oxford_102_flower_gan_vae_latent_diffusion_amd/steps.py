@@ -301,7 +301,7 @@ class VAEGANTrainer:
     """VAE-GAN training step (configs 1/2 of BASELINE.json), v2:1060-1134.
 
     Data parallel (world_size > 1; one process per GPU, each with a shard of the batch): the step is the
-    GLOBAL-batch step of the reference for everything except BatchNorm -
+    GLOBAL-batch step of the reference -
       * the gradients of the autoencoder and of the discriminator are all-reduced (flat buffers, two collectives) and
         averaged inside the Adam kernels;
       * the six loss terms that drive the balancing coefficients (v2:1107-1125) are all-reduced first, so every rank uses
@@ -309,14 +309,21 @@ class VAEGANTrainer:
         (v2:385): the mean part is averaged, the sum part added over ranks, and its gradient scaled by world_size
         (shard gradients are averaged afterwards);
       * the class-centre EMA (v2:369-378) runs on the all-gathered latents and labels, identically on every rank;
-      * Discriminator64's BatchNorm uses the LOCAL shard statistics (what torch DDP does without SyncBatchNorm): the
-        adversarial gradients therefore differ from a single-process run on the global batch; everything else is exact.
+      * Discriminator64's BatchNorm layers are synchronised (sync_bn=True, the default): the per-channel sums of the
+        forward and of the backward are all-reduced (2C doubles per layer per pass, fl_batchnorm_sums ->
+        fl_batchnorm_*_from_sums), so the statistics, the running buffers and dx are those of the global batch.
+        sync_bn=False keeps the LOCAL shard statistics (what torch DDP does without SyncBatchNorm); the adversarial
+        gradients then differ from a single-process run on the global batch.
     Collectives are eager torch.distributed calls (RCCL on GPUs), so the data-parallel step is not graph-captured."""
 
     def __init__(self, autoencoder, discriminator, vgg, lr=1e-4, lambda_cls=0.1, lambda_center=0.05, lambda_vgg=0.4,
-                 lambda_gan=0.2, process_group=None, world_size=1):
+                 lambda_gan=0.2, process_group=None, world_size=1, sync_bn=True):
         self.ae, self.disc, self.vgg = autoencoder, discriminator, vgg
         self.pg, self.world = process_group, int(world_size)
+        self.bn_sync = None
+        if self.world > 1 and sync_bn:
+            import torch.distributed as dist
+            self.bn_sync = lambda t: dist.all_reduce(t, group=self.pg)
         dev = next(autoencoder.parameters()).device
         self.dev = dev
         self.fp = FlatParams(autoencoder, ("classifier.",))
@@ -391,8 +398,9 @@ class VAEGANTrainer:
         else:
             cen = zero
         # ---- discriminator update (v2:1097-1102) ----
-        p_real, S_r = engine_bwd.disc_fwd(D, data)
-        p_fake, S_f = engine_bwd.disc_fwd(D, recon)  # recon_x.detach(): no gradient reaches the AE from here
+        bns = dict(sync=self.bn_sync, world=self.world)
+        p_real, S_r = engine_bwd.disc_fwd(D, data, **bns)
+        p_fake, S_f = engine_bwd.disc_fwd(D, recon, **bns)  # recon_x.detach(): no gradient reaches the AE from here
         l_real, l_fake = ops.bce_fwd(p_real, 1.0), ops.bce_fwd(p_fake, 0.0)
         d_loss = ops.axpby(0.5, l_real, 0.5, l_fake)
         Gr, _ = engine_bwd.disc_bwd(D, S_r, ops.bce_bwd(p_real, 1.0, 0.5), need_wgrad=True, need_dx=False)
@@ -402,20 +410,21 @@ class VAEGANTrainer:
         allreduce_grads(self.dfp, W, self.pg)
         self.d_opt.step(gscale=1.0 / W)
         # ---- generator adversarial term with the UPDATED discriminator (v2:1105) ----
-        p_adv, S_a = engine_bwd.disc_fwd(D, recon)
+        p_adv, S_a = engine_bwd.disc_fwd(D, recon, **bns)
         adv = ops.bce_fwd(p_adv, 1.0)
         # ---- device-side loss balancing (v2:1107-1125) ----
         if W > 1:
             import torch.distributed as dist
-            # [recon, percep, kl mean part, adv, ce, centre | kl batch-sum part]: means are averaged, the sum is summed
+            # [recon, percep, kl mean part, adv, ce, centre | kl batch-sum part | d_loss]: means are averaged, the sum is summed
             tv = torch.zeros(8, dtype=torch.float32, device=self.dev)
             reg = ops.colsum(musq.view(B, 1), alpha=1e-4) if musq is not None else zero
             klmean = ops.axpby(1.0, kl, -1.0, reg) if musq is not None else zero
             for i, tsr in enumerate((recon_loss, percep, klmean, adv, ce, cen)):
                 ops.axpby(1.0 / W, tsr, out=tv[i:i + 1])
             ops.axpby(1.0, reg, out=tv[6:7])
+            ops.axpby(1.0 / W, d_loss, out=tv[7:8])
             dist.all_reduce(tv, group=self.pg)
-            recon_loss, percep, adv, ce, cen = tv[0:1], tv[1:2], tv[3:4], tv[4:5], tv[5:6]
+            recon_loss, percep, adv, ce, cen, d_loss = tv[0:1], tv[1:2], tv[3:4], tv[4:5], tv[5:6], tv[7:8]
             kl = ops.axpby(1.0, tv[2:3], 1.0, tv[6:7])
         for i, tsr in enumerate((recon_loss, percep, kl, adv, ce, cen)):
             ops.axpby(1.0, tsr, out=self.terms[i:i + 1])

@@ -187,6 +187,60 @@ def test_batchnorm(dev, B, C, H, W):
     close(nchw(y), F.batch_norm(x.double(), rm_ref, rv_ref, w.double(), b.double(), False, 0.1, 1e-5), tol=2e-5)
 
 
+@pytest.mark.parametrize("B,C,H,W,shards", [(4, 128, 16, 16, 2), (6, 512, 4, 4, 3), (8, 64, 32, 32, 4)])
+def test_batchnorm_synchronised_shards(dev, B, C, H, W, shards):
+    """SyncBatchNorm rule: each shard reduces its own sums, the (emulated) all-reduce adds them, and every shard then
+    normalises / back-propagates with the statistics of the whole batch - vs F.batch_norm on the whole batch."""
+    x = rnd(B, C, H, W, seed=1) * 2 + 0.5
+    w, b, dy = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), rnd(B, C, H, W, seed=4)
+    rm, rv = 0.1 * rnd(C, seed=5), 1 + 0.1 * rnd(C, seed=6).abs()
+    xg, wg, bg = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    ref = F.leaky_relu(F.batch_norm(xg, rm_ref, rv_ref, wg, bg, True, 0.1, 1e-5), 0.2)
+    ref.backward(dy.double())
+    per = B // shards
+    xs = [nhwc(x[i * per:(i + 1) * per]).to(dev) for i in range(shards)]
+    dys = [nhwc(dy[i * per:(i + 1) * per]).to(dev) for i in range(shards)]
+    wd, bd = w.to(dev), b.to(dev)
+
+    class Exchange:  # two passes: collect every shard's sums, then hand each shard the total
+        def __init__(self):
+            self.parts, self.total = [], None
+
+        def __call__(self, t):
+            if self.total is None:
+                self.parts.append(t.clone())
+            else:
+                t.copy_(self.total)
+
+        def close(self):
+            self.total = torch.stack(self.parts).sum(0)
+
+    ex = Exchange()
+    for xd in xs:
+        ops.batchnorm_stats(xd, wd, bd, rm.to(dev), rv.to(dev), True, sync=ex, world=shards)
+    ex.close()
+    stats, dw_sum, db_sum = [], 0, 0
+    for i, xd in enumerate(xs):
+        rmd, rvd = rm.to(dev), rv.to(dev)
+        st = ops.batchnorm_stats(xd, wd, bd, rmd, rvd, True, sync=ex, world=shards)
+        stats.append(st)
+        y = ops.affine_act(xd, st[0], st[1], act=3, act_param=0.2)
+        close(nchw(y), ref[i * per:(i + 1) * per], tol=2e-5)
+        close(rmd, rm_ref, tol=2e-6)
+        close(rvd, rv_ref, tol=2e-6)
+    ex = Exchange()
+    for xd, dyd, st in zip(xs, dys, stats):
+        ops.batchnorm_bwd(dyd, xd, st[0], st[1], wd, st[2], st[3], act=3, act_param=0.2, sync=ex, world=shards)
+    ex.close()
+    for i, (xd, dyd, st) in enumerate(zip(xs, dys, stats)):
+        dx, dw, db = ops.batchnorm_bwd(dyd, xd, st[0], st[1], wd, st[2], st[3], act=3, act_param=0.2, sync=ex, world=shards)
+        close(nchw(dx), xg.grad[i * per:(i + 1) * per], tol=5e-5)
+        dw_sum, db_sum = dw_sum + dw.double(), db_sum + db.double()
+    close(dw_sum, wg.grad, tol=5e-5)   # local shares add up to the global-batch dw / db
+    close(db_sum, bg.grad, tol=5e-5)
+
+
 @pytest.mark.parametrize("rows,D", [(8, 256), (256, 1024), (4, 32768), (3, 512)])
 def test_layernorm(dev, rows, D):
     x = rnd(rows, D, seed=1) * 2 + 0.3

@@ -1,8 +1,9 @@
 """Data-parallel VAE-GAN step: two ranks (gloo, both on cuda:0 - one-GPU box), each with half of a global
-batch, against the oracle's single-process step on the whole batch. lambda_gan = 0 keeps Discriminator64's BatchNorm
-(local shard statistics by design) out of the autoencoder's gradient, so everything compared here must be exact:
-the globally balanced loss terms, the averaged autoencoder gradient (incl. the batch-SUM mu^2 term of the KL), the
-post-step weights and the class-centre EMA over the gathered batch."""
+batch, against the oracle's single-process step on the whole batch: the globally balanced loss terms, the averaged
+autoencoder gradient (incl. the batch-SUM mu^2 term of the KL), the post-step weights and the class-centre EMA over
+the gathered batch. With lambda_gan = 0 Discriminator64 stays out of the autoencoder's gradient; with the reference's
+lambda_gan = 0.2 the synchronised BatchNorm (global-batch statistics in forward and backward) is on the path too, and
+the discriminator's own gradients, update and running statistics are compared as well."""
 import os
 import socket
 
@@ -31,7 +32,7 @@ def _inputs():
     return data, labels, eps, m1, m2
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, lambda_gan):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -49,33 +50,38 @@ def _worker(rank, world, port, ret):
     D.load_state_dict(pinit.procedural_state_dict(D.state_dict(), 43))
     ae, D = ae.to(dev).train(), D.to(dev).train()
     vgg = M.VGGPerceptualLoss(dev, state_dict=pinit.procedural_state_dict(pinit.vgg16_features16_shapes(""), 7))
-    tr = steps.VAEGANTrainer(ae, D, vgg, lr=1e-4, lambda_gan=0.0, process_group=dist.group.WORLD, world_size=world)
+    tr = steps.VAEGANTrainer(ae, D, vgg, lr=1e-4, lambda_gan=lambda_gan, process_group=dist.group.WORLD, world_size=world)
     out = tr.step(data[sl].to(dev), labels[sl].to(dev), epoch=200, num_epochs=300, lr=1e-4, reparam_eps=eps[sl].to(dev),
                   cls_masks=(m1[sl].to(dev), m2[sl].to(dev)))
     torch.cuda.synchronize()
     keys = ("encoder.initial_conv.0.weight", "encoder.res2.conv1.weight", "encoder.fc_mu.0.weight", "decoder.fc.3.weight",
             "decoder.up2.0.weight", "classifier.4.weight", "encoder.res1.sa.conv.weight", "decoder.up1.1.weight")
-    ret[rank] = dict(losses={k: float(out[k]) for k in ("total", "recon", "perceptual", "kl", "cls", "center")},
+    dkeys = ("model.0.weight", "model.2.weight", "model.3.weight", "model.6.bias", "model.8.weight", "model.11.weight")
+    ret[rank] = dict(losses={k: float(out[k]) for k in ("total", "recon", "perceptual", "kl", "cls", "center", "adv", "d_loss")},
                      grad_norm=float(out["grad_norm"]),
+                     d_grads={k: (tr.dfp.gviews[k].detach().cpu().reshape(-1)[:4096] / world).clone() for k in dkeys},
+                     d_state={k: D.state_dict()[k].detach().cpu().reshape(-1)[:4096].clone()
+                              for k in dkeys + ("model.3.running_mean", "model.9.running_var")},
                      grads={k: tr.fp.gviews[k].detach().cpu().reshape(-1)[:4096].clone() for k in keys},
                      params={k: ae.state_dict()[k].detach().cpu().reshape(-1)[:4096].clone() for k in keys},
                      centers=ae.class_centers.detach().cpu().clone())
     dist.destroy_process_group()
 
 
-def test_dp_vae_gan_step_equals_global_batch_step(dev):
+@pytest.mark.parametrize("lambda_gan", [0.0, 0.2])
+def test_dp_vae_gan_step_equals_global_batch_step(dev, lambda_gan):
     from oracle import procedural_init as pinit, v2_oracle as O
     from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, lambda_gan), nprocs=world, join=True)
     assert len(ret) == world
     data, labels, eps, m1, m2 = _inputs()
     ae_sd = pinit.procedural_state_dict(M.SimpleAutoencoder().state_dict(), 42)
     d_sd = pinit.procedural_state_dict(M.Discriminator64().state_dict(), 43)
     vgg_sd = {"feature_extractor." + k: v for k, v in pinit.procedural_state_dict(pinit.vgg16_features16_shapes(""), 7).items()}
-    ref = O.vae_gan_step(ae_sd, d_sd, vgg_sd, data, labels, eps, epoch=200, num_epochs=300, lr=1e-4, lambda_gan=0.0,
+    ref = O.vae_gan_step(ae_sd, d_sd, vgg_sd, data, labels, eps, epoch=200, num_epochs=300, lr=1e-4, lambda_gan=lambda_gan,
                          cls_masks=(m1, m2))
 
     def close(a, b, tol, what):
@@ -86,12 +92,18 @@ def test_dp_vae_gan_step_equals_global_batch_step(dev):
     for r in range(world):
         got = ret[r]
         for k, kk in (("total", "total"), ("recon", "recon"), ("perceptual", "perceptual"), ("kl", "kl"), ("cls", "cls"),
-                      ("center", "center")):
+                      ("center", "center"), ("adv", "adv"), ("d_loss", "d_loss")):
             close(got["losses"][k], ref["losses"][kk], 3e-4, "rank %d loss %s" % (r, k))
         close(got["grad_norm"], ref["grad_norm"], 2e-3, "rank %d grad norm" % r)
         for k, gv in got["grads"].items():
             close(gv, ref["ae_grads"][k].reshape(-1)[:4096], 2e-3, "rank %d grad %s" % (r, k))
         close(got["centers"], ref["centers"], 1e-5, "rank %d centres" % r)
+        for k, gv in got["d_grads"].items():  # sum over ranks / world == gradient of the global-batch d_loss
+            close(gv, ref["d_grads"][k].reshape(-1)[:4096], 2e-3, "rank %d D grad %s" % (r, k))
+        for k in ("model.3.running_mean", "model.9.running_var"):  # SyncBN: unbiased variance over world*B*HW
+            close(got["d_state"][k], ref["new_d_sd"][k].reshape(-1)[:4096], 1e-4, "rank %d %s" % (r, k))
     # both ranks hold the same weights after the step
     for k in ret[0]["params"]:
         assert torch.equal(ret[0]["params"][k], ret[1]["params"][k]), "ranks diverged: " + k
+    for k in ret[0]["d_state"]:
+        assert torch.equal(ret[0]["d_state"][k], ret[1]["d_state"][k]), "ranks diverged (D): " + k
