@@ -270,6 +270,19 @@ int fl_update_centers(float* centers, const float* z, const int64_t* labels, flo
                       fl_stream_t stream);                                                            /* v2:369-378 */
 int fl_balance_losses(const float* terms, const float* weights, float* coeff, float* total, fl_stream_t stream); /* v2:1107-1125 */
 
+/* Training-image transform on the device. Replaces transform_train (v2:24-30) / transform_test
+ * (v2:32-35) + DataLoader(..., num_workers=2) (v2:1303) for a pre-resized uint8 image cache resident in HBM:
+ *   cache  (N,64,64,3) uint8 NHWC - Resize((64,64)) already applied when the cache was built
+ *   labels (N) int64 or NULL; index (B) int64 rows of the cache for this batch, or NULL = rows 0..B-1
+ *   params (B,16) int32 or NULL. NULL / word 14 != 0 = transform_test (ToTensor only). Otherwise per image:
+ *     [0] horizontal flip; [1..6] Image.rotate's inverse affine map in Pillow's 16.16 fixed point (a0 a1 a2 a3 a4 a5,
+ *     half-pixel offsets folded into a2/a5), nearest neighbour, zero fill; [7..10] ColorJitter op order
+ *     (0 brightness, 1 contrast, 2 saturation, 3 none); [11..13] float32 bits of the three factors.
+ *   out (B,3,64,64) float32 NCHW in [0,1] (ToTensor); labels_out (B) int64 or NULL.
+ * Bit-exact with Pillow's integer / float32 arithmetic (oracle/augment_oracle.py). Out-of-range indices are clamped. */
+int fl_augment_batch(const uint8_t* cache, const int64_t* labels, const int64_t* index, const int32_t* params, float* out,
+                     int64_t* labels_out, int B, int N, int H, int W, fl_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * Backward of the residual-block tail (v2:173-177) and VAE-GAN-only helpers.
  *   A: dw = dout*swish'(u*att + x) ; da = att(1-att) * sum_c dw*u

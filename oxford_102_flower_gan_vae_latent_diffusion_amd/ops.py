@@ -688,6 +688,28 @@ def gather_rows(table, idx):
     return out
 
 
+def augment_batch(cache, index=None, params=None, labels=None, out=None):
+    """transform_train / transform_test (v2:24-35) on a uint8 NHWC image cache resident in HBM.
+    cache (N,64,64,3) uint8; index (B,) int64 or None; params (B,16) int32 or None (= ToTensor only);
+    labels (N,) int64 or None -> data (B,3,64,64) float32 [, labels (B,) int64]."""
+    for t, dt in ((cache, torch.uint8), (index, torch.int64), (params, torch.int32), (labels, torch.int64)):
+        if t is None:
+            continue
+        if not t.is_cuda or not t.is_contiguous() or t.dtype != dt:
+            raise RuntimeError("augment_batch: need contiguous device tensors (uint8 cache, int64 index/labels, int32 params)")
+    N, H, W, C = cache.shape
+    if C != 3:
+        raise ValueError("augment_batch: the cache is NHWC RGB")
+    B = index.shape[0] if index is not None else (params.shape[0] if params is not None else N)
+    if params is not None and tuple(params.shape) != (B, 16):
+        raise ValueError("augment_batch: params must be (B,16) int32, got %s for B=%d" % (tuple(params.shape), B))
+    if out is None:
+        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=cache.device)
+    lab_out = torch.empty((B,), dtype=torch.int64, device=cache.device) if labels is not None else None
+    _lib.call("fl_augment_batch", _p(cache), _p(labels), _p(index), _p(params), _p(out), _p(lab_out), B, N, H, W, _stream())
+    return (out, lab_out) if labels is not None else out
+
+
 def update_centers(centers, z, labels, momentum=0.9):
     _chk(centers, z, labels)
     _lib.call("fl_update_centers", _p(centers), _p(z), _p(labels), float(momentum), z.shape[0], z.shape[1],
