@@ -1,0 +1,308 @@
+// 3x3 / stride 1 / pad 1 convolution with pre-split weights, "halo tile" variant of the implicit-GEMM conv in gemm.hip
+// (the six ResidualBlock convs of the frozen encoder, v2:159-178, two thirds of the DDPM step's matrix work).
+//
+// The generic kernel stages one [128 pixels x 32 channels] A tile per TAP: nine global->LDS round trips (loads, zero
+// selects, ds_writes, a block barrier) per 32-channel chunk. Its timing ablations (profiles/r01_conv_kernel_pmc.md) put
+// ~10 % of the kernel on that staging. Here the tile's input HALO ((rows+2) x (W+2) pixels x 32 channels, <= 29 KB) is
+// staged ONCE per channel chunk and all nine taps read their MFMA A fragments from it at shifted LDS addresses (the tap
+// shift is an immediate offset): one staging pass and one barrier per 9 x 48 MFMAs instead of per 48.
+//
+// Same math as gemm_kernel<.., B_FRAGS, .., SPLIT=6>: fp32 activations split exactly into three bf16 pieces in
+// registers, weights pre-split once (fl_split_pack_weight, identical buffer), six piece products per k-group on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulation; same 128x128 block / 64x64 wave tiling, same epilogue (bias, activation,
+// row-major store, optional LayerNorm2d column sums per 64-row slab). Only the ORDER of the K loop differs
+// (channel chunk outer, tap inner), i.e. fp32 re-association.
+//
+// Specialisation (host-checked): kh = kw = 3, stride 1, pad 1, H == W in {8, 16, 32}, Cin % 32 == 0, Cout % 128 == 0,
+// B*H*W % 128 == 0. A 128-pixel tile is 128/W whole output rows (W = 32: 4 rows, 16: 8 rows) or two whole 8x8 images.
+#include "fl_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+struct Split3 {
+  u32x4_t h, m, l;
+};
+// x = h + m + l exactly, pieces by truncation (see gemm.hip); 8 values = this lane's k-slots of one 16-k group
+__device__ __forceinline__ Split3 split3(const float4& q0, const float4& q1) {
+  const float x[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+  float r1[8], r2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xFFFF0000u);
+    r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xFFFF0000u);
+  }
+  Split3 s;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    s.h[p] = __builtin_amdgcn_perm(__float_as_uint(x[2 * p + 1]), __float_as_uint(x[2 * p]), 0x07060302u);
+    s.m[p] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * p + 1]), __float_as_uint(r1[2 * p]), 0x07060302u);
+    s.l[p] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * p + 1]), __float_as_uint(r2[2 * p]), 0x07060302u);
+  }
+  return s;
+}
+
+struct HaloArgs {
+  const float* x;
+  const u32x4_t* wsplit;
+  const float* bias;
+  float* y;
+  float* stats;
+  int Cin, Cout, M, tiles_n, act;
+  float act_param;
+};
+
+constexpr int LROW = 36;  // floats per staged pixel: 32 channels + 4 pad (conflict-free ds_read_b128 over consecutive pixels)
+
+template <int W>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WM = 64, WN = 64;
+  constexpr int R = BM / W;                 // output rows per tile
+  constexpr int RI = R < W ? R : W;         // ... per image
+  constexpr int NI = R / RI;                // images per tile (2 for 8x8)
+  constexpr int HR = RI + 2, HC = W + 2;    // halo rows / cols per image
+  constexpr int P = NI * HR * HC;           // staged pixels
+  constexpr int ITEMS = P * 8;              // float4 per chunk
+  constexpr int NST = (ITEMS + 255) / 256;  // float4 per thread per chunk
+  constexpr int TILE_F = P * LROW;
+  static_assert(2 * TILE_F * 4 <= 64 * 1024, "two halo buffers fit the static LDS limit");
+  __shared__ __attribute__((aligned(16))) float smem[2 * TILE_F];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // XCD-aware tile order (as gemm.hip): each XCD owns a contiguous range of tiles -> halo rows shared through its L2
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile_m0 = (tile / g.tiles_n) * BM;
+  const int tile_n0 = (tile % g.tiles_n) * BN;
+  const int img0 = tile_m0 / (W * W);
+  const int oy0 = (tile_m0 - img0 * (W * W)) / W;  // 0 when the tile holds whole images
+  const int Cin = g.Cin, nC = Cin >> 5;
+
+  // ---- staging descriptors: item i = tid + 256 j -> (halo pixel i >> 3, float4 i & 7); invariant over channel chunks
+  int goff[NST];
+  unsigned vmask = 0u;
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const int i = tid + 256 * j;
+    const int pix = i >> 3, c4 = i & 7;
+    const int nl = pix / (HR * HC), rem = pix - nl * (HR * HC);
+    const int hy = rem / HC, hx = rem - hy * HC;
+    const int iy = oy0 - 1 + hy, ix = hx - 1;
+    const bool ok = (i < ITEMS) && ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
+    goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+  const int sdst = (tid >> 3) * LROW + (tid & 7) * 4;  // item j lands at sdst + j * 32 * LROW floats
+
+  float4 stg[NST];
+  auto stage_load = [&](int c) {
+    const float* xc = g.x + c * 32;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) stg[j] = *reinterpret_cast<const float4*>(xc + goff[j]);
+  };
+  auto stage_store = [&](int buf) {
+    float* dst = smem + buf * TILE_F + sdst;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      if ((j + 1) * 256 > ITEMS && tid + 256 * j >= ITEMS) continue;  // only the last pass can run past the halo
+      const bool ok = (vmask >> j) & 1u;
+      float4 v = stg[j];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;  // padding ring
+      *reinterpret_cast<float4*>(dst + j * 32 * LROW) = v;
+    }
+  };
+
+  // ---- A fragment addresses: tile row r -> halo pixel of tap (0,0); tap (dy,dx) adds (dy*HC + dx)*LROW floats
+  int abase[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int r = wr * WM + tm * 32 + li;
+    const int nl = r / (RI * W), rr = r - nl * (RI * W);
+    const int oyl = rr / W, ox = rr - oyl * W;
+    abase[tm] = ((nl * HR + oyl) * HC + ox) * LROW + 4 * lh;
+  }
+  // ---- B fragments: [16-k group][32-col tile][piece][lane] x 16 B, straight from global / L2
+  const int nt32 = g.Cout >> 5;
+  const u32x4_t* bbase = g.wsplit + (size_t)((tile_n0 + wc * WN) >> 5) * (3 * 64) + lane;
+  const int gpt = Cin >> 4;  // 16-k groups per tap
+  auto load_bp = [&](int g16, u32x4_t (&bp)[TN][3]) {
+    const u32x4_t* b = bbase + (size_t)g16 * nt32 * (3 * 64);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bp[tn][p] = b[(tn * 3 + p) * 64];
+  };
+  // quarters 2h, 2h+1 of tap `tap` from LDS buffer S
+  auto frag_load = [&](const float* S, int tapoff, int h, float4 (&f0)[TM], float4 (&f1)[TM]) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const float* p = S + abase[tm] + tapoff + 16 * h;
+      f0[tm] = *reinterpret_cast<const float4*>(p);
+      f1[tm] = *reinterpret_cast<const float4*>(p + 8);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  // 24 MFMAs on pieces split earlier, interleaved 1 : 8 with the VALU split of the NEXT half-step's fragments
+  auto mfma_and_split = [&](const Split3 (&sa)[TM], const u32x4_t (&bp)[TN][3], Split3 (&sn)[TM], const float4 (&n0)[TM],
+                            const float4 (&n1)[TM]) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) sn[tm] = split3(n0[tm], n1[tm]);
+#define FL_PIECE(pa, pi)                                                                                       \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)         \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, sa[tm].pa),        \
+                                                              __builtin_bit_cast(bf16x8_t, bp[tn][pi]), acc[tm][tn], 0, 0, 0);
+    FL_PIECE(l, 0) FL_PIECE(h, 2) FL_PIECE(m, 1) FL_PIECE(m, 0) FL_PIECE(h, 1) FL_PIECE(h, 0)  // smallest terms first
+#undef FL_PIECE
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+    for (int i = 0; i < 6 * TM * TN - 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+  };
+
+  Split3 saA[TM], saB[TM];
+  u32x4_t bpA[TN][3], bpB[TN][3];
+  float4 f0[TM], f1[TM];
+
+  // ---- prologue: chunk 0 staged, first fragments split
+  stage_load(0);
+  load_bp(0, bpA);
+  stage_store(0);
+  __syncthreads();
+  frag_load(smem, 0, 0, f0, f1);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) saA[tm] = split3(f0[tm], f1[tm]);
+
+  // one tap = two half-steps. STAGE: the next chunk's halo loads are issued right AFTER this tap's first fragment
+  // loads - vmcnt retires in order, so a long-latency load issued BEFORE them would be waited for at once; issued
+  // after, it has a whole half-step (24 MFMAs) before the next wait reaches it.
+  auto tap_body = [&](auto stage_tag, int tap, const float* S, int tapoff, int tapnext, int gc, int cn) {
+    // half 0 runs on (saA, bpA); prefetch half 1 of this tap
+    load_bp(tap * gpt + gc + 1, bpB);
+    frag_load(S, tapoff, 1, f0, f1);
+    if constexpr (decltype(stage_tag)::value) stage_load(cn);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_and_split(saA, bpA, saB, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    // half 1 runs on (saB, bpB); prefetch half 0 of the next tap
+    load_bp((tap + 1) * gpt + gc, bpA);
+    frag_load(S, tapnext, 0, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_and_split(saB, bpB, saA, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  for (int c = 0; c < nC; ++c) {
+    const float* S = smem + (c & 1) * TILE_F;
+    const int cn = c + 1 < nC ? c + 1 : c;  // clamped: the last chunk re-stages itself (never read)
+    const int gc = 2 * c;                    // first 16-k group of this chunk inside a tap
+    tap_body(std::true_type{}, 0, S, 0, LROW, gc, cn);  // next halo in flight under the remaining 8 taps
+    int tapoff = LROW;
+#pragma unroll 1
+    for (int tap = 1; tap < 8; ++tap) {
+      const int dyn = (tap + 1) / 3, dxn = (tap + 1) - 3 * dyn;
+      const int tapnext = (dyn * HC + dxn) * LROW;
+      tap_body(std::false_type{}, tap, S, tapoff, tapnext, gc, cn);
+      tapoff = tapnext;
+    }
+    // tap 8 (dy = dx = 2): half 0 as above
+    load_bp(8 * gpt + gc + 1, bpB);
+    frag_load(S, tapoff, 1, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_and_split(saA, bpA, saB, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    // half 1: the next chunk's halo goes to the other buffer (last read before the previous barrier), one barrier,
+    // then the first fragments of the next chunk are prefetched under this chunk's last 24 MFMAs
+    stage_store((c + 1) & 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_bp(2 * cn, bpA);
+    frag_load(smem + ((c + 1) & 1) * TILE_F, 0, 0, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_and_split(saB, bpB, saA, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+  float st1[TN], st2[TN], bv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    st1[tn] = st2[tn] = 0.f;
+    bv[tn] = g.bias ? g.bias[tile_n0 + wc * WN + tn * 32 + li] : 0.f;
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = tile_m0 + wr * WM + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      float* yrow = g.y + (size_t)m * g.Cout + tile_n0 + wc * WN + li;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const float v = fl::apply_act(acc[tm][tn][e] + bv[tn], g.act, g.act_param);
+        yrow[tn * 32] = v;
+        st1[tn] += v;
+        st2[tn] += v * v;
+      }
+    }
+  }
+  // fused LayerNorm2d statistics: this wave's 64 rows lie in one image (H*W % 64 == 0): one slab of (sum y, sum y^2)
+  if (g.stats) {
+    const int grp = (tile_m0 + wr * WM) / WM;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const float a = st1[tn] + __shfl_xor(st1[tn], 32, 64);
+      const float b = st2[tn] + __shfl_xor(st2[tn], 32, 64);
+      const int col = tile_n0 + wc * WN + tn * 32 + li;
+      if (lh == 0) {
+        g.stats[((size_t)grp * 2) * g.Cout + col] = a;
+        g.stats[((size_t)grp * 2 + 1) * g.Cout + col] = b;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+namespace fl {
+
+bool conv3x3_halo_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
+  if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1 && H == W && (W == 8 || W == 16 || W == 32))) return false;
+  if (Cin % 32 || Cout % 128 || ((long long)B * H * W) % 128) return false;
+  if ((long long)B * H * W * Cin >= (1ll << 31) || (reinterpret_cast<uintptr_t>(x) & 15)) return false;
+  return true;
+}
+
+int launch_conv3x3_halo(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int B, int H, int W,
+                        int Cin, int Cout, int act, float act_param, hipStream_t s) {
+  HaloArgs g;
+  g.x = x; g.wsplit = reinterpret_cast<const u32x4_t*>(wsplit); g.bias = bias; g.y = y; g.stats = stats;
+  g.Cin = Cin; g.Cout = Cout; g.M = B * H * W; g.tiles_n = Cout / 128; g.act = act; g.act_param = act_param;
+  const int blocks = (g.M / 128) * g.tiles_n;
+  if (W == 32) hipLaunchKernelGGL(conv3x3_halo_kernel<32>, dim3(blocks), dim3(256), 0, s, g);
+  else if (W == 16) hipLaunchKernelGGL(conv3x3_halo_kernel<16>, dim3(blocks), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(conv3x3_halo_kernel<8>, dim3(blocks), dim3(256), 0, s, g);
+  return fl::check_launch("conv3x3_halo_kernel");
+}
+
+}  // namespace fl

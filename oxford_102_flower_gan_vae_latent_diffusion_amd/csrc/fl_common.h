@@ -86,4 +86,9 @@ int conv3x3_c4_o64_slabs(int H, int W);
 int launch_conv3x3_c4_o64(const float* x, const float* wp, const float* bias, float* y, float* partial, int B, int H, int W,
                           int act, float act_param, hipStream_t s);
 
+// 3x3 / stride 1 / pad 1 conv with pre-split weights, halo staged once per channel chunk (conv_halo.hip)
+bool conv3x3_halo_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+int launch_conv3x3_halo(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int B, int H, int W,
+                        int Cin, int Cout, int act, float act_param, hipStream_t s);
+
 }  // namespace fl

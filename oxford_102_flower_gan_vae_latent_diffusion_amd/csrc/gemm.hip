@@ -632,9 +632,13 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GArgs g)
     __builtin_amdgcn_sched_barrier(0);
     mfma_and_split(sa01, bpA, sa23, fa2, fa3);
     __builtin_amdgcn_sched_barrier(0);
+#if !(FL_ABLATE & 2)
     store_A(buf ^ 1, sta, sma);
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !(FL_ABLATE & 4)
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
     load_bp(2 * kc + 2, bpA);
     frag_load(0, As + (buf ^ 1) * A_TILE, As, fa0, fb0);
@@ -1051,7 +1055,11 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
   g.splitk = 1;
   g.chunks_per_split = fl::cdiv(g.K, BK);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int rc = launch_cfg3<128, 128, 2, 2, A_KC_CONV, B_FRAGS, 2, 6>(g, 1, s);
+  // 3x3 s1 p1 on 8/16/32-wide square maps: the halo-tile kernel stages each channel chunk once for all nine taps
+  static const bool halo_on = !(getenv("FL_CONV_HALO") && getenv("FL_CONV_HALO")[0] == '0');
+  const int rc = (halo_on && fl::conv3x3_halo_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad))
+                     ? fl::launch_conv3x3_halo(x, wsplit, bias, y, g.stats, B, H, W, Cin, Cout, act, act_param, s)
+                     : launch_cfg3<128, 128, 2, 2, A_KC_CONV, B_FRAGS, 2, 6>(g, 1, s);
   if (rc || !stats) return rc;
   hipLaunchKernelGGL(conv_inorm_finalize, dim3(fl::cdiv((long long)B * Cout, 256)), dim3(256), 0, s, g.stats, ln_w, ln_b, eps,
                      scale, shift, mean, rstd, B, HW, Cout, HW / 64);

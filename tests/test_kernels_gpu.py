@@ -494,7 +494,10 @@ def test_conv_fwd_both_gemm_math_modes(dev, each_gemm_math):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,HW,k,s,p", [(2, 128, 128, 32, 3, 1, 1), (3, 64, 128, 64, 4, 2, 1), (1, 256, 256, 16, 3, 1, 1),
-                                                 (2, 256, 512, 16, 4, 2, 1)])
+                                                 (2, 256, 512, 16, 4, 2, 1),
+                                                 # 3x3 s1 p1 on 8/16/32-wide maps -> halo-tile kernel (conv_halo.hip):
+                                                 # two whole 8x8 images per tile, tiles below the top image row, 4 N-tiles
+                                                 (4, 512, 512, 8, 3, 1, 1), (3, 128, 256, 32, 3, 1, 1), (2, 256, 128, 16, 3, 1, 1)])
 def test_conv_fwd_presplit_weight(dev, B, Cin, Cout, HW, k, s, p):
     """pre-split weight fragments (B_FRAGS) give the same convolution as the in-kernel split and as fp64 F.conv2d,
     with and without the fused LayerNorm2d statistics."""
@@ -512,7 +515,7 @@ def test_conv_fwd_presplit_weight(dev, B, Cin, Cout, HW, k, s, p):
     y2, (sc, sh, mean, rstd) = ops.conv2d_fwd_presplit(xh, ws, geom, bias.to(dev), s, p, ln_w=lw.to(dev), ln_b=lb.to(dev))
     close(nchw(y2), ref, tol=1e-5)
     y3, (sc3, sh3, _, _) = ops.conv2d_fwd_instnorm(xh, wp, bias.to(dev), s, p, lw.to(dev), lb.to(dev), 1e-5)
-    close(y2, y3.cpu(), tol=2e-6)
+    close(y2, y3.cpu(), tol=5e-6)  # same math, different K order (halo kernel: channel chunk outer, tap inner)
     close(sc, sc3.cpu(), tol=1e-5)
     close(sh, sh3.cpu(), tol=1e-5)
     close(mean, ref.mean((2, 3)), tol=1e-5)
