@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 SPLIT_PIECE_PRODUCTS = 6        # bf16 MFMAs issued per fp32 product in the default "split" GEMM math (flowers_hip.h)
+PMC_TRAFFIC_HALO = 2.73e8         # HBM-side bytes per launch of conv3x3_halo_kernel (rocprofv3 PMC, profiles/r01_conv_kernel_pmc.md)
 # algorithmic GFLOP per image (forward MACs x2): frozen encoder fwd + denoiser fwd+bwd (3x fwd)
 GFLOP_PER_IMAGE_STEP = 2.748
 
@@ -43,11 +44,13 @@ def conv_shapes(B):
 
 
 def measure_dominant_kernel(dev, B, reps=5):
-    """HIP-event timing (on the stream the kernels are launched on = torch's current stream) of every launch of
-    the dominant kernel in one step -> average duration per launch and algorithmic TFLOP/s."""
+    """HIP-event timing (on the stream the kernels are launched on = torch's current stream) of every conv launch of the
+    frozen encoder in one step, grouped by the kernel that serves it -> average duration per launch and algorithmic
+    TFLOP/s per kernel. In split mode the six 3x3 ResidualBlock convs run on conv3x3_halo_kernel (the dominant kernel
+    by time), the three 4x4 stride-2 convs on gemm_kernel<..B_FRAGS>; in fp32 mode all nine run on gemm_kernel."""
     from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
-    tot_t, tot_f, n = 0.0, 0.0, 0
-    per = []
+    groups = {}
+    halo_on = os.environ.get("FL_CONV_HALO", "1") != "0"
     for name, b, H, W, Ci, Co, k, s, p in conv_shapes(B):
         x = torch.empty(b, H, W, Ci, device=dev)
         ops.philox_fill(x, seed=11, mode=0)
@@ -57,11 +60,13 @@ def measure_dominant_kernel(dev, B, reps=5):
         Ho = (H + 2 * p - k) // s + 1
         y = torch.empty(b, Ho, Ho, Co, device=dev)
         # the launch the step itself makes: in split mode the frozen encoder's weights are pre-split (B_FRAGS operand)
-        if ops.get_gemm_math() == "split" and ops.presplit_ok(Ci, Co, Ho * Ho):
+        presplit = ops.get_gemm_math() == "split" and ops.presplit_ok(Ci, Co, Ho * Ho)
+        if presplit:
             wsp, geom = ops.split_pack_weight(w), tuple(w.shape)
             run = lambda: ops.conv2d_fwd_presplit(x, wsp, geom, bias, s, p, out=y)
         else:
             run = lambda: ops.conv2d_fwd(x, w, bias, s, p, out=y)
+        kern = "halo" if (presplit and halo_on and k == 3 and s == 1 and H in (8, 16, 32)) else "gemm"
         run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -71,11 +76,18 @@ def measure_dominant_kernel(dev, B, reps=5):
         e1.synchronize()
         ms = e0.elapsed_time(e1) / reps
         fl = 2.0 * b * Ho * Ho * Co * k * k * Ci
-        per.append((name, ms, fl / ms / 1e9))
-        tot_t += ms
-        tot_f += fl
-        n += 1
-    return dict(avg_ms=tot_t / n, tflops=tot_f / tot_t / 1e9, flop_per_launch=tot_f / n, launches=n, per=per)
+        by = 4.0 * b * (H * H * Ci + Ho * Ho * Co) + (6.0 if presplit else 4.0) * Co * k * k * Ci  # x + y + weights, once
+        gr = groups.setdefault(kern, dict(t=0.0, f=0.0, by=0.0, n=0, per=[]))
+        gr["t"] += ms
+        gr["f"] += fl
+        gr["by"] += by
+        gr["n"] += 1
+        gr["per"].append((name, ms, fl / ms / 1e9))
+    res = {}
+    for kname, gr in groups.items():
+        res[kname] = dict(avg_ms=gr["t"] / gr["n"], tflops=gr["f"] / gr["t"] / 1e9, flop_per_launch=gr["f"] / gr["n"],
+                          bytes_per_launch=gr["by"] / gr["n"], launches=gr["n"], total_ms=gr["t"], per=gr["per"])
+    return res
 
 
 def split_vs_fp32_mfma(dev):
@@ -265,18 +277,26 @@ def main():
     }
     if rank == 0 and world == 1:
         if not a.no_roofline:
-            r = measure_dominant_kernel(dev, B)
-            log("dominant kernel: %.1f TFLOP/s avg over %d launches" % (r["tflops"], r["launches"]))
+            groups = measure_dominant_kernel(dev, B)
+            dom = max(groups, key=lambda kname: groups[kname]["total_ms"])
+            r = groups[dom]
+            log("dominant kernel (%s): %.1f TFLOP/s avg over %d launches" % (dom, r["tflops"], r["launches"]))
             split = gemm_math == "split"
             # the fraction is taken against the peak of the instruction the kernel actually issues: in split mode one
             # algorithmic fp32 flop costs SPLIT_PIECE_PRODUCTS bf16 flops, so the ceiling of the scheme is 2500/6 TFLOP/s
             peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PIECE_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS
+            math_note = ("6 x v_mfma_f32_32x32x16_bf16 per 16 k on exact bf16 pieces of the fp32 operands" if split
+                         else "v_mfma_f32_32x32x2_f32")
+            names = {"halo": "conv3x3_halo_kernel<W> (3x3 s1 p1 conv of the encoder's ResidualBlocks: input halo staged once "
+                             "per 32-channel chunk, weights pre-split, " + math_note + ")",
+                     "gemm": ("gemm_kernel<128,128,2,2,A_KC_CONV,B_FRAGS> (implicit-GEMM conv, weights pre-split, " if split
+                              else "gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> (implicit-GEMM conv, ") + math_note + ")"}
+            # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, averaged over the kernel's
+            # launches at B=256; profiles/r01_conv_kernel_pmc.md). Not re-measured live: PMC needs the profiler.
+            traffic = {"halo": PMC_TRAFFIC_HALO, "gemm": 4.4e8 if split else 4.08e8}[dom] if B == 256 else None
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": ("gemm_kernel<128,128,2,2,A_KC_CONV,B_FRAGS> (implicit-GEMM conv, weights pre-split, " if split
-                           else "gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> (implicit-GEMM conv, ") +
-                          ("6 x v_mfma_f32_32x32x16_bf16 per 16 k on exact bf16 pieces of the fp32 operands)" if split
-                           else "v_mfma_f32_32x32x2_f32)"),
+                "kernel": names[dom],
                 "achieved": r["tflops"],
                 "peak": peak,
                 "unit": "TFLOP/s",
@@ -285,13 +305,16 @@ def main():
                               if split else "fp32 dense MFMA peak",
                 "achieved_over_fp32_mfma_peak": r["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                 "split_vs_fp32_mfma_max_rel_diff": split_vs_fp32_mfma(dev),
-                # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, averaged over the 9
-                # launches at B=256; profiles/r01_conv_kernel_pmc.md). Not re-measured live: PMC needs the profiler.
-                "traffic": (4.4e8 if split else 4.08e8) if B == 256 else None,
-                "algorithmic_bytes_per_launch": 1.86e8 if B == 256 else None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": r["bytes_per_launch"],
                 "avg_launch_ms": r["avg_ms"],
                 "algorithmic_gflop_per_launch": r["flop_per_launch"] / 1e9,
                 "launches_per_step": r["launches"],
+                "other_conv_kernels": {names[kname]: {"achieved": g2["tflops"], "frac": g2["tflops"] / peak,
+                                                      "avg_launch_ms": g2["avg_ms"], "launches_per_step": g2["launches"]}
+                                       for kname, g2 in groups.items() if kname != dom},
+                "all_encoder_convs_tflops": sum(g2["flop_per_launch"] * g2["launches"] for g2 in groups.values())
+                                            / sum(g2["total_ms"] for g2 in groups.values()) / 1e9,
                 "step_frac_of_mfma_roofline": (GFLOP_PER_IMAGE_STEP * B * a.steps / dt / 1e3) / peak,
             }
         if not a.no_cpu_baseline:
