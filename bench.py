@@ -47,7 +47,7 @@ def measure_dominant_kernel(dev, B, reps=5):
     """HIP-event timing (on the stream the kernels are launched on = torch's current stream) of every conv launch of the
     frozen encoder in one step, grouped by the kernel that serves it -> average duration per launch and algorithmic
     TFLOP/s per kernel. In split mode the six 3x3 ResidualBlock convs run on conv3x3_halo_kernel (the dominant kernel
-    by time), the three 4x4 stride-2 convs on gemm_kernel<..B_FRAGS>; in fp32 mode all nine run on gemm_kernel."""
+    by time), the three 4x4 stride-2 convs on conv4x4s2_halo_kernel; in fp32 mode all nine run on gemm_kernel."""
     from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
     groups = {}
     halo_on = os.environ.get("FL_CONV_HALO", "1") != "0"
@@ -66,7 +66,11 @@ def measure_dominant_kernel(dev, B, reps=5):
             run = lambda: ops.conv2d_fwd_presplit(x, wsp, geom, bias, s, p, out=y)
         else:
             run = lambda: ops.conv2d_fwd(x, w, bias, s, p, out=y)
-        kern = "halo" if (presplit and halo_on and k == 3 and s == 1 and H in (8, 16, 32)) else "gemm"
+        kern = "gemm"
+        if presplit and halo_on and k == 3 and s == 1 and H in (8, 16, 32):
+            kern = "halo"
+        elif presplit and halo_on and k == 4 and s == 2 and H in (16, 32, 64):
+            kern = "halo_s2"
         run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -289,11 +293,13 @@ def main():
                          else "v_mfma_f32_32x32x2_f32")
             names = {"halo": "conv3x3_halo_kernel<W> (3x3 s1 p1 conv of the encoder's ResidualBlocks: input halo staged once "
                              "per 32-channel chunk, weights pre-split, " + math_note + ")",
+                     "halo_s2": "conv4x4s2_halo_kernel<Wo> (4x4 s2 p1 down-sampling convs: input halo staged once per 16-channel "
+                                "chunk, weights pre-split, " + math_note + ")",
                      "gemm": ("gemm_kernel<128,128,2,2,A_KC_CONV,B_FRAGS> (implicit-GEMM conv, weights pre-split, " if split
                               else "gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> (implicit-GEMM conv, ") + math_note + ")"}
             # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, averaged over the kernel's
             # launches at B=256; profiles/r01_conv_kernel_pmc.md). Not re-measured live: PMC needs the profiler.
-            traffic = {"halo": PMC_TRAFFIC_HALO, "gemm": 4.4e8 if split else 4.08e8}[dom] if B == 256 else None
+            traffic = {"halo": PMC_TRAFFIC_HALO, "halo_s2": None, "gemm": 4.4e8 if split else 4.08e8}[dom] if B == 256 else None
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": names[dom],

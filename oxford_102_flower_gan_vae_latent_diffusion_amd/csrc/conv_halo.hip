@@ -282,27 +282,261 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 4x4 / stride 2 / pad 1 variant (the three down-sampling convs of the encoder, v2:191-213). The input halo of a
+// 128-output tile is (2 rows + 2) x (2 Wo + 2) pixels - ~4x the 3x3 case - so it is staged per SIXTEEN channels
+// ([pixel][16 + 4 pad] floats, <= 52.8 KB, single buffer, 2 blocks per CU): one 16-k group per tap and chunk, sixteen taps
+// = sixteen half-steps between stagings. With one buffer a chunk boundary needs two barriers (all reads done -> store ->
+// stores visible); the next chunk's global loads are still in flight under the whole chunk.
+constexpr int LROW2 = 20;
+
+template <int WO>
+__global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WM = 64, WN = 64;
+  constexpr int W = 2 * WO;                   // input height = width
+  constexpr int R = BM / WO;                  // output rows per tile
+  constexpr int RI = R < WO ? R : WO;         // ... per image
+  constexpr int NI = R / RI;
+  constexpr int HR = 2 * RI + 2, HC = 2 * WO + 2;
+  constexpr int P = NI * HR * HC;
+  constexpr int ITEMS = P * 4;                // float4 per 16-channel chunk
+  constexpr int NST = (ITEMS + 255) / 256;
+  constexpr int TILE_F = P * LROW2;
+  static_assert(TILE_F * 4 <= 64 * 1024, "the halo buffer fits the static LDS limit");
+  __shared__ __attribute__((aligned(16))) float smem[TILE_F];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile_m0 = (tile / g.tiles_n) * BM;
+  const int tile_n0 = (tile % g.tiles_n) * BN;
+  const int img0 = tile_m0 / (WO * WO);
+  const int oy0 = (tile_m0 - img0 * (WO * WO)) / WO;
+  const int Cin = g.Cin, nC = Cin >> 4;
+
+  int goff[NST];
+  unsigned vmask = 0u;
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const int i = tid + 256 * j;
+    const int pix = i >> 2, c4 = i & 3;
+    const int nl = pix / (HR * HC), rem = pix - nl * (HR * HC);
+    const int hy = rem / HC, hx = rem - hy * HC;
+    const int iy = 2 * oy0 - 1 + hy, ix = hx - 1;
+    const bool ok = (i < ITEMS) && ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
+    goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+  const int sdst = (tid >> 2) * LROW2 + (tid & 3) * 4;  // item j lands at sdst + j * 64 * LROW2 floats
+
+  float4 stg[NST];
+  auto stage_load = [&](int c) {
+    const float* xc = g.x + c * 16;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) stg[j] = *reinterpret_cast<const float4*>(xc + goff[j]);
+  };
+  auto stage_store = [&]() {
+    float* dst = smem + sdst;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      if ((j + 1) * 256 > ITEMS && tid + 256 * j >= ITEMS) continue;
+      const bool ok = (vmask >> j) & 1u;
+      float4 v = stg[j];
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<float4*>(dst + j * 64 * LROW2) = v;
+    }
+  };
+
+  int abase[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int r = wr * WM + tm * 32 + li;
+    const int nl = r / (RI * WO), rr = r - nl * (RI * WO);
+    const int oyl = rr / WO, ox = rr - oyl * WO;
+    abase[tm] = ((nl * HR + 2 * oyl) * HC + 2 * ox) * LROW2 + 4 * lh;
+  }
+  const int nt32 = g.Cout >> 5;
+  const u32x4_t* bbase = g.wsplit + (size_t)((tile_n0 + wc * WN) >> 5) * (3 * 64) + lane;
+  const int gpt = Cin >> 4;
+  auto load_bp = [&](int g16, u32x4_t (&bp)[TN][3]) {
+    const u32x4_t* b = bbase + (size_t)g16 * nt32 * (3 * 64);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bp[tn][p] = b[(tn * 3 + p) * 64];
+  };
+  auto frag_load = [&](int tapoff, float4 (&f0)[TM], float4 (&f1)[TM]) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const float* p = smem + abase[tm] + tapoff;
+      f0[tm] = *reinterpret_cast<const float4*>(p);
+      f1[tm] = *reinterpret_cast<const float4*>(p + 8);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  auto mfma_and_split = [&](const Split3 (&sa)[TM], const u32x4_t (&bp)[TN][3], Split3 (&sn)[TM], const float4 (&n0)[TM],
+                            const float4 (&n1)[TM]) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) sn[tm] = split3(n0[tm], n1[tm]);
+#define FL_PIECE(pa, pi)                                                                                       \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)         \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, sa[tm].pa),        \
+                                                              __builtin_bit_cast(bf16x8_t, bp[tn][pi]), acc[tm][tn], 0, 0, 0);
+    FL_PIECE(l, 0) FL_PIECE(h, 2) FL_PIECE(m, 1) FL_PIECE(m, 0) FL_PIECE(h, 1) FL_PIECE(h, 0)
+#undef FL_PIECE
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+    for (int i = 0; i < 6 * TM * TN - 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+  };
+
+  Split3 saA[TM], saB[TM];
+  u32x4_t bpA[TN][3], bpB[TN][3];
+  float4 f0[TM], f1[TM];
+
+  stage_load(0);
+  load_bp(0, bpA);
+  stage_store();
+  __syncthreads();
+  frag_load(0, f0, f1);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) saA[tm] = split3(f0[tm], f1[tm]);
+
+  // taps 2 tp (on saA, bpA) and 2 tp + 1 (on saB, bpB): tap t = (dy, dx) = (t >> 2, t & 3) -> 2 tp = (tp >> 1, 2 (tp & 1))
+  auto pair_body = [&](auto stage_tag, int tp, int c, int cn) {
+    const int off0 = ((tp >> 1) * HC + 2 * (tp & 1)) * LROW2;
+    const int tn2 = tp + 1, off2 = ((tn2 >> 1) * HC + 2 * (tn2 & 1)) * LROW2;
+    load_bp((2 * tp + 1) * gpt + c, bpB);
+    frag_load(off0 + LROW2, f0, f1);
+    if constexpr (decltype(stage_tag)::value) stage_load(cn);  // after the fragment loads: see tap_body above
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_and_split(saA, bpA, saB, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_bp((2 * tp + 2) * gpt + c, bpA);
+    frag_load(off2, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_and_split(saB, bpB, saA, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  for (int c = 0; c < nC; ++c) {
+    const int cn = c + 1 < nC ? c + 1 : c;
+    pair_body(std::true_type{}, 0, c, cn);
+#pragma unroll 1
+    for (int tp = 1; tp < 7; ++tp) pair_body(std::false_type{}, tp, c, cn);
+    // taps 14, 15
+    load_bp(15 * gpt + c, bpB);
+    frag_load((3 * HC + 3) * LROW2, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_and_split(saA, bpA, saB, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    // every read of this chunk has been issued: drain, let everyone finish, replace the halo, publish it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stage_store();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_bp(cn, bpA);
+    frag_load(0, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_and_split(saB, bpB, saA, f0, f1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  float st1[TN], st2[TN], bv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    st1[tn] = st2[tn] = 0.f;
+    bv[tn] = g.bias ? g.bias[tile_n0 + wc * WN + tn * 32 + li] : 0.f;
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = tile_m0 + wr * WM + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      float* yrow = g.y + (size_t)m * g.Cout + tile_n0 + wc * WN + li;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const float v = fl::apply_act(acc[tm][tn][e] + bv[tn], g.act, g.act_param);
+        yrow[tn * 32] = v;
+        st1[tn] += v;
+        st2[tn] += v * v;
+      }
+    }
+  }
+  if (g.stats) {
+    const int grp = (tile_m0 + wr * WM) / WM;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const float a = st1[tn] + __shfl_xor(st1[tn], 32, 64);
+      const float b = st2[tn] + __shfl_xor(st2[tn], 32, 64);
+      const int col = tile_n0 + wc * WN + tn * 32 + li;
+      if (lh == 0) {
+        g.stats[((size_t)grp * 2) * g.Cout + col] = a;
+        g.stats[((size_t)grp * 2 + 1) * g.Cout + col] = b;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 namespace fl {
 
 bool conv3x3_halo_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
-  if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1 && H == W && (W == 8 || W == 16 || W == 32))) return false;
-  if (Cin % 32 || Cout % 128 || ((long long)B * H * W) % 128) return false;
-  if ((long long)B * H * W * Cin >= (1ll << 31) || (reinterpret_cast<uintptr_t>(x) & 15)) return false;
-  return true;
+  if (Cin % 32 || Cout % 128 || (reinterpret_cast<uintptr_t>(x) & 15) || H != W) return false;
+  if ((long long)B * H * W * Cin >= (1ll << 31)) return false;
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && (W == 8 || W == 16 || W == 32)) return ((long long)B * H * W) % 128 == 0;
+  if (kh == 4 && kw == 4 && stride == 2 && pad == 1 && (W == 16 || W == 32 || W == 64)) return ((long long)B * (H / 2) * (W / 2)) % 128 == 0;
+  return false;
 }
 
+// 3x3 s1 p1 (W in 8/16/32) or 4x4 s2 p1 (input W in 16/32/64); the caller checked conv3x3_halo_applicable
 int launch_conv3x3_halo(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int B, int H, int W,
                         int Cin, int Cout, int act, float act_param, hipStream_t s) {
+  return launch_conv_halo(x, wsplit, bias, y, stats, B, H, W, Cin, Cout, 3, act, act_param, s);
+}
+
+int launch_conv_halo(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int B, int H, int W,
+                     int Cin, int Cout, int ksize, int act, float act_param, hipStream_t s) {
   HaloArgs g;
   g.x = x; g.wsplit = reinterpret_cast<const u32x4_t*>(wsplit); g.bias = bias; g.y = y; g.stats = stats;
-  g.Cin = Cin; g.Cout = Cout; g.M = B * H * W; g.tiles_n = Cout / 128; g.act = act; g.act_param = act_param;
-  const int blocks = (g.M / 128) * g.tiles_n;
-  if (W == 32) hipLaunchKernelGGL(conv3x3_halo_kernel<32>, dim3(blocks), dim3(256), 0, s, g);
-  else if (W == 16) hipLaunchKernelGGL(conv3x3_halo_kernel<16>, dim3(blocks), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL(conv3x3_halo_kernel<8>, dim3(blocks), dim3(256), 0, s, g);
-  return fl::check_launch("conv3x3_halo_kernel");
+  g.Cin = Cin; g.Cout = Cout; g.tiles_n = Cout / 128; g.act = act; g.act_param = act_param;
+  if (ksize == 3) {
+    g.M = B * H * W;
+    const int blocks = (g.M / 128) * g.tiles_n;
+    if (W == 32) hipLaunchKernelGGL(conv3x3_halo_kernel<32>, dim3(blocks), dim3(256), 0, s, g);
+    else if (W == 16) hipLaunchKernelGGL(conv3x3_halo_kernel<16>, dim3(blocks), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(conv3x3_halo_kernel<8>, dim3(blocks), dim3(256), 0, s, g);
+  } else {
+    const int Wo = W / 2;
+    g.M = B * Wo * Wo;
+    const int blocks = (g.M / 128) * g.tiles_n;
+    if (Wo == 32) hipLaunchKernelGGL(conv4x4s2_halo_kernel<32>, dim3(blocks), dim3(256), 0, s, g);
+    else if (Wo == 16) hipLaunchKernelGGL(conv4x4s2_halo_kernel<16>, dim3(blocks), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(conv4x4s2_halo_kernel<8>, dim3(blocks), dim3(256), 0, s, g);
+  }
+  return fl::check_launch("conv_halo_kernel");
 }
 
 }  // namespace fl

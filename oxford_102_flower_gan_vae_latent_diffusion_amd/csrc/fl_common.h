@@ -90,5 +90,7 @@ int launch_conv3x3_c4_o64(const float* x, const float* wp, const float* bias, fl
 bool conv3x3_halo_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 int launch_conv3x3_halo(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int B, int H, int W,
                         int Cin, int Cout, int act, float act_param, hipStream_t s);
+int launch_conv_halo(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int B, int H, int W,
+                     int Cin, int Cout, int ksize, int act, float act_param, hipStream_t s);
 
 }  // namespace fl

@@ -1055,10 +1055,10 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
   g.splitk = 1;
   g.chunks_per_split = fl::cdiv(g.K, BK);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // 3x3 s1 p1 on 8/16/32-wide square maps: the halo-tile kernel stages each channel chunk once for all nine taps
+  // 3x3 s1 p1 / 4x4 s2 p1 on the encoder's square maps: the halo-tile kernels stage each channel chunk once for all taps
   static const bool halo_on = !(getenv("FL_CONV_HALO") && getenv("FL_CONV_HALO")[0] == '0');
   const int rc = (halo_on && fl::conv3x3_halo_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad))
-                     ? fl::launch_conv3x3_halo(x, wsplit, bias, y, g.stats, B, H, W, Cin, Cout, act, act_param, s)
+                     ? fl::launch_conv_halo(x, wsplit, bias, y, g.stats, B, H, W, Cin, Cout, kh, act, act_param, s)
                      : launch_cfg3<128, 128, 2, 2, A_KC_CONV, B_FRAGS, 2, 6>(g, 1, s);
   if (rc || !stats) return rc;
   hipLaunchKernelGGL(conv_inorm_finalize, dim3(fl::cdiv((long long)B * Cout, 256)), dim3(256), 0, s, g.stats, ln_w, ln_b, eps,
