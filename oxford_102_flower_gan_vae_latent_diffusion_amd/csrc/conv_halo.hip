@@ -16,6 +16,7 @@
 // Specialisation (host-checked): kh = kw = 3, stride 1, pad 1, H == W in {8, 16, 32}, Cin % 32 == 0, Cout % 128 == 0,
 // B*H*W % 128 == 0. A 128-pixel tile is 128/W whole output rows (W = 32: 4 rows, 16: 8 rows) or two whole 8x8 images.
 #include "fl_common.h"
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -57,6 +58,13 @@ struct HaloArgs {
 
 constexpr int LROW = 36;  // floats per staged pixel: 32 channels + 4 pad (conflict-free ds_read_b128 over consecutive pixels)
 
+// dynamic LDS of conv3x3_halo_kernel<W> (must mirror the constants inside the kernel)
+constexpr int halo3_lds_bytes(int W) {
+  const int R = 128 / W, RI = R < W ? R : W, NI = R / RI, HR = RI + 2, HC = W + 2;
+  const int RPAD = W == 32 ? 0 : ((W - HC) * LROW % 64 + 64) % 64;
+  return 2 * NI * HR * (HC * LROW + RPAD) * 4;
+}
+
 template <int W>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) {
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WM = 64, WN = 64;
@@ -67,9 +75,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) 
   constexpr int P = NI * HR * HC;           // staged pixels
   constexpr int ITEMS = P * 8;              // float4 per chunk
   constexpr int NST = (ITEMS + 255) / 256;  // float4 per thread per chunk
-  constexpr int TILE_F = P * LROW;
-  static_assert(2 * TILE_F * 4 <= 64 * 1024, "two halo buffers fit the static LDS limit");
-  __shared__ __attribute__((aligned(16))) float smem[2 * TILE_F];
+  // halo row pitch (floats). The 32 lanes of a fragment read are 32 consecutive output pixels; for W < 32 they span several
+  // output rows, and the jump between rows must look like "the next W pixels" to the LDS banks (64 x 4 B), i.e.
+  // RP == W * LROW (mod 64): then every lane hits the banks it would hit in the conflict-free W = 32 case (PMC: 46-63 %
+  // of the LDS cycles were bank conflicts with the dense pitch HC * LROW).
+  constexpr int RPAD = W == 32 ? 0 : ((W - HC) * LROW % 64 + 64) % 64;
+  constexpr int RP = HC * LROW + RPAD;
+  constexpr int TILE_F = NI * HR * RP;
+  static_assert(2 * TILE_F * 4 <= 80 * 1024, "two halo buffers, two blocks per CU (160 KB of LDS)");
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * TILE_F floats (halo3_lds_bytes; may exceed 64 KB)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) 
   const int Cin = g.Cin, nC = Cin >> 5;
 
   // ---- staging descriptors: item i = tid + 256 j -> (halo pixel i >> 3, float4 i & 7); invariant over channel chunks
-  int goff[NST];
+  int goff[NST], sdst[NST];
   unsigned vmask = 0u;
 #pragma unroll
   for (int j = 0; j < NST; ++j) {
@@ -100,9 +114,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) 
     const int iy = oy0 - 1 + hy, ix = hx - 1;
     const bool ok = (i < ITEMS) && ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
     goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
+    sdst[j] = (nl * HR + hy) * RP + hx * LROW + c4 * 4;
     vmask |= (ok ? 1u : 0u) << j;
   }
-  const int sdst = (tid >> 3) * LROW + (tid & 7) * 4;  // item j lands at sdst + j * 32 * LROW floats
 
   float4 stg[NST];
   auto stage_load = [&](int c) {
@@ -111,25 +125,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) 
     for (int j = 0; j < NST; ++j) stg[j] = *reinterpret_cast<const float4*>(xc + goff[j]);
   };
   auto stage_store = [&](int buf) {
-    float* dst = smem + buf * TILE_F + sdst;
+    float* dst = smem + buf * TILE_F;
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
       if ((j + 1) * 256 > ITEMS && tid + 256 * j >= ITEMS) continue;  // only the last pass can run past the halo
       const bool ok = (vmask >> j) & 1u;
       float4 v = stg[j];
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;  // padding ring
-      *reinterpret_cast<float4*>(dst + j * 32 * LROW) = v;
+      *reinterpret_cast<float4*>(dst + sdst[j]) = v;
     }
   };
 
-  // ---- A fragment addresses: tile row r -> halo pixel of tap (0,0); tap (dy,dx) adds (dy*HC + dx)*LROW floats
+  // ---- A fragment addresses: tile row r -> halo pixel of tap (0,0); tap (dy,dx) adds dy*RP + dx*LROW floats
   int abase[TM];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int r = wr * WM + tm * 32 + li;
     const int nl = r / (RI * W), rr = r - nl * (RI * W);
     const int oyl = rr / W, ox = rr - oyl * W;
-    abase[tm] = ((nl * HR + oyl) * HC + ox) * LROW + 4 * lh;
+    abase[tm] = (nl * HR + oyl) * RP + ox * LROW + 4 * lh;
   }
   // ---- B fragments: [16-k group][32-col tile][piece][lane] x 16 B, straight from global / L2
   const int nt32 = g.Cout >> 5;
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) 
 #pragma unroll 1
     for (int tap = 1; tap < 8; ++tap) {
       const int dyn = (tap + 1) / 3, dxn = (tap + 1) - 3 * dyn;
-      const int tapnext = (dyn * HC + dxn) * LROW;
+      const int tapnext = dyn * RP + dxn * LROW;
       tap_body(std::false_type{}, tap, S, tapoff, tapnext, gc, cn);
       tapoff = tapnext;
     }
@@ -525,9 +539,15 @@ int launch_conv_halo(const float* x, const void* wsplit, const float* bias, floa
   if (ksize == 3) {
     g.M = B * H * W;
     const int blocks = (g.M / 128) * g.tiles_n;
-    if (W == 32) hipLaunchKernelGGL(conv3x3_halo_kernel<32>, dim3(blocks), dim3(256), 0, s, g);
-    else if (W == 16) hipLaunchKernelGGL(conv3x3_halo_kernel<16>, dim3(blocks), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(conv3x3_halo_kernel<8>, dim3(blocks), dim3(256), 0, s, g);
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(32));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(16));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(8));
+    });
+    if (W == 32) hipLaunchKernelGGL(conv3x3_halo_kernel<32>, dim3(blocks), dim3(256), halo3_lds_bytes(32), s, g);
+    else if (W == 16) hipLaunchKernelGGL(conv3x3_halo_kernel<16>, dim3(blocks), dim3(256), halo3_lds_bytes(16), s, g);
+    else hipLaunchKernelGGL(conv3x3_halo_kernel<8>, dim3(blocks), dim3(256), halo3_lds_bytes(8), s, g);
   } else {
     const int Wo = W / 2;
     g.M = B * Wo * Wo;
