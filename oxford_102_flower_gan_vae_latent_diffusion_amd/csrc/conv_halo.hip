@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) 
 // ---------------------------------------------------------------------------------------------------------------------
 // 4x4 / stride 2 / pad 1 variant (the three down-sampling convs of the encoder, v2:191-213). The input halo of a
 // 128-output tile is (2 rows + 2) x (2 Wo + 2) pixels - ~4x the 3x3 case - so it is staged per SIXTEEN channels
-// ([pixel][16 + 4 pad] floats, <= 52.8 KB, single buffer, 2 blocks per CU): one 16-k group per tap and chunk, sixteen taps
+// ([pixel][16 + 4 pad] floats, even / odd columns in separate planes, <= 60 KB, single buffer, 2 blocks per CU): one 16-k group per tap and chunk, sixteen taps
 // = sixteen half-steps between stagings. With one buffer a chunk boundary needs two barriers (all reads done -> store ->
 // stores visible); the next chunk's global loads are still in flight under the whole chunk.
 constexpr int LROW2 = 20;
@@ -316,7 +316,15 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g
   constexpr int P = NI * HR * HC;
   constexpr int ITEMS = P * 4;                // float4 per 16-channel chunk
   constexpr int NST = (ITEMS + 255) / 256;
-  constexpr int TILE_F = P * LROW2;
+  // LDS image: even and odd input columns in separate planes, so that the 32 lanes of a fragment read (32 consecutive
+  // output pixels = input columns 2 ox + dx) are CONSECUTIVE pixels of one plane: pitch 20 floats = an odd multiple of
+  // 4 banks -> 16 lanes cover the 64 banks exactly once. Row pitch RP2 makes the jump to the next output row (two
+  // input rows) look like "the next WO pixels" to the banks (2 RP2 == WO * 20 mod 64), as in the 3x3 kernel.
+  constexpr int HCP = WO + 1;                 // pixels per plane row
+  constexpr int RP2 = WO == 32 ? HCP * LROW2 : (WO == 16 ? 352 : 208);
+  static_assert(RP2 >= HCP * LROW2 && (WO == 32 || (2 * RP2 - WO * LROW2) % 64 == 0), "row pitch");
+  constexpr int PLANE_F = NI * HR * RP2;
+  constexpr int TILE_F = 2 * PLANE_F;
   static_assert(TILE_F * 4 <= 64 * 1024, "the halo buffer fits the static LDS limit");
   __shared__ __attribute__((aligned(16))) float smem[TILE_F];
 
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g
   const int oy0 = (tile_m0 - img0 * (WO * WO)) / WO;
   const int Cin = g.Cin, nC = Cin >> 4;
 
-  int goff[NST];
+  int goff[NST], sdst[NST];
   unsigned vmask = 0u;
 #pragma unroll
   for (int j = 0; j < NST; ++j) {
@@ -346,9 +354,9 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g
     const int iy = 2 * oy0 - 1 + hy, ix = hx - 1;
     const bool ok = (i < ITEMS) && ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
     goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
+    sdst[j] = (hx & 1) * PLANE_F + (nl * HR + hy) * RP2 + (hx >> 1) * LROW2 + c4 * 4;
     vmask |= (ok ? 1u : 0u) << j;
   }
-  const int sdst = (tid >> 2) * LROW2 + (tid & 3) * 4;  // item j lands at sdst + j * 64 * LROW2 floats
 
   float4 stg[NST];
   auto stage_load = [&](int c) {
@@ -357,14 +365,13 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g
     for (int j = 0; j < NST; ++j) stg[j] = *reinterpret_cast<const float4*>(xc + goff[j]);
   };
   auto stage_store = [&]() {
-    float* dst = smem + sdst;
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
       if ((j + 1) * 256 > ITEMS && tid + 256 * j >= ITEMS) continue;
       const bool ok = (vmask >> j) & 1u;
       float4 v = stg[j];
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      *reinterpret_cast<float4*>(dst + j * 64 * LROW2) = v;
+      *reinterpret_cast<float4*>(smem + sdst[j]) = v;
     }
   };
 
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g
     const int r = wr * WM + tm * 32 + li;
     const int nl = r / (RI * WO), rr = r - nl * (RI * WO);
     const int oyl = rr / WO, ox = rr - oyl * WO;
-    abase[tm] = ((nl * HR + 2 * oyl) * HC + 2 * ox) * LROW2 + 4 * lh;
+    abase[tm] = (nl * HR + 2 * oyl) * RP2 + ox * LROW2 + 4 * lh;  // tap (dy, dx): + (dx & 1) PLANE_F + dy RP2 + (dx >> 1) LROW2
   }
   const int nt32 = g.Cout >> 5;
   const u32x4_t* bbase = g.wsplit + (size_t)((tile_n0 + wc * WN) >> 5) * (3 * 64) + lane;
@@ -436,10 +443,10 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g
 
   // taps 2 tp (on saA, bpA) and 2 tp + 1 (on saB, bpB): tap t = (dy, dx) = (t >> 2, t & 3) -> 2 tp = (tp >> 1, 2 (tp & 1))
   auto pair_body = [&](auto stage_tag, int tp, int c, int cn) {
-    const int off0 = ((tp >> 1) * HC + 2 * (tp & 1)) * LROW2;
-    const int tn2 = tp + 1, off2 = ((tn2 >> 1) * HC + 2 * (tn2 & 1)) * LROW2;
+    const int off0 = (tp >> 1) * RP2 + (tp & 1) * LROW2;               // tap 2 tp: even plane
+    const int tn2 = tp + 1, off2 = (tn2 >> 1) * RP2 + (tn2 & 1) * LROW2;
     load_bp((2 * tp + 1) * gpt + c, bpB);
-    frag_load(off0 + LROW2, f0, f1);
+    frag_load(off0 + PLANE_F, f0, f1);                                 // tap 2 tp + 1: same shift, odd plane
     if constexpr (decltype(stage_tag)::value) stage_load(cn);  // after the fragment loads: see tap_body above
     __builtin_amdgcn_sched_barrier(0);
     mfma_and_split(saA, bpA, saB, f0, f1);
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g
     for (int tp = 1; tp < 7; ++tp) pair_body(std::false_type{}, tp, c, cn);
     // taps 14, 15
     load_bp(15 * gpt + c, bpB);
-    frag_load((3 * HC + 3) * LROW2, f0, f1);
+    frag_load(PLANE_F + 3 * RP2 + LROW2, f0, f1);  // tap 15 = (3, 3): odd plane, shift 1
     __builtin_amdgcn_sched_barrier(0);
     mfma_and_split(saA, bpA, saB, f0, f1);
     __builtin_amdgcn_sched_barrier(0);
