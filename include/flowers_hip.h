@@ -68,6 +68,12 @@ size_t fl_gemm_workspace_bytes(int M, int N, int K);
  *      rounding noise of an fp32 accumulation over K >= 64 terms. Unaligned operands always take mode 0. */
 int fl_set_gemm_math(int mode);
 int fl_get_gemm_math(void);
+/* Split-K policy of the GEMM launcher: a GEMM whose grid has fewer tiles than `tiles` is split along K (+ one reduce
+ * launch) so that it fills the chip. Default 160. 0 disables split-K. A stream that shares the chip with another one
+ * (the denoiser next to the frozen encoder, steps.DDPMTrainer.capture_pipelined) lowers it while it captures its graph:
+ * results are the same up to fp32 summation order. Process-wide, read at launch time. */
+int fl_set_gemm_splitk_tiles(int tiles);
+int fl_get_gemm_splitk_tiles(void);
 int fl_gemm_f32(const float* A, int64_t lda, int a_layout,
                 const float* B, int64_t ldb, int b_layout,
                 float* C, int64_t ldc, int M, int N, int K,

@@ -897,6 +897,11 @@ int launch_cfg(GArgs g, int classes, hipStream_t stream) {
 }
 
 // tile-shape + split-K policy. `classes` = 4 for transposed conv, else 1.
+// split-K is used when a GEMM's grid has fewer tiles than this (default 160: fill the 256 CUs of an otherwise idle
+// chip). A caller whose GEMMs share the chip with another stream (the denoiser next to the frozen encoder) lowers it:
+// there the extra reduce launch costs more than the idle CUs it would fill (fl_set_gemm_splitk_tiles).
+int g_splitk_tiles = 160;
+
 template <int AM, int BMODE>
 int launch_gemm(GArgs g, int classes, void* ws, size_t ws_bytes, hipStream_t stream, int* wm_out = nullptr) {
   if (g.M <= 0 || g.N <= 0) return FL_OK;
@@ -922,7 +927,7 @@ int launch_gemm(GArgs g, int classes, void* ws, size_t ws_bytes, hipStream_t str
   g.splitk = 1;
   g.chunks_per_split = nk;
   g.ws = reinterpret_cast<float*>(ws);
-  if (g.out_mode == OUT_ROWMAJOR && classes == 1 && tiles < 160 && nk >= 8 && ws != nullptr) {
+  if (g.out_mode == OUT_ROWMAJOR && classes == 1 && tiles < g_splitk_tiles && nk >= 8 && ws != nullptr) {
     int want = (int)((320 + tiles - 1) / tiles);
     int maxs = nk / 4;
     if (want > maxs) want = maxs;
@@ -1072,6 +1077,13 @@ int fl_set_gemm_math(int mode) {
   return FL_OK;
 }
 int fl_get_gemm_math(void) { return gemm_math(); }
+
+int fl_set_gemm_splitk_tiles(int tiles) {
+  FL_REQUIRE(tiles >= 0 && tiles <= 4096, "fl_set_gemm_splitk_tiles: %d out of range", tiles);
+  g_splitk_tiles = tiles;
+  return FL_OK;
+}
+int fl_get_gemm_splitk_tiles(void) { return g_splitk_tiles; }
 
 size_t fl_conv2d_fwd_instnorm_workspace_bytes(int B, int Ho, int Wo, int Cout) {
   return ((size_t)B * Ho * Wo / 32 + 1) * 2 * (size_t)Cout * sizeof(float);

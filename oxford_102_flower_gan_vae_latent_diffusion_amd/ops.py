@@ -81,6 +81,13 @@ def set_gemm_math(mode):
     _lib.call("fl_set_gemm_math", {"fp32": 0, "split": 1}[mode] if isinstance(mode, str) else int(mode))
 
 
+def set_gemm_splitk_tiles(tiles):
+    """GEMM grids with fewer tiles than this are split along K (default 160). Returns the previous value."""
+    old = int(_lib.load().fl_get_gemm_splitk_tiles())
+    _lib.call("fl_set_gemm_splitk_tiles", int(tiles))
+    return old
+
+
 def get_gemm_math():
     return "split" if _lib.load().fl_get_gemm_math() else "fp32"
 

@@ -222,7 +222,10 @@ class DDPMTrainer:
         self.static_data, self.static_labels = data, labels
         for _ in range(2):
             self.step(data, labels)
-        self.sE, self.sU = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        # stream priorities (experiment knob, default none): FL_PIPE_PRIO="e,u", -1 = high
+        import os
+        pe, pu = (int(v) for v in os.environ.get("FL_PIPE_PRIO", "0,0").split(","))
+        self.sE, self.sU = torch.cuda.Stream(dev, priority=pe), torch.cuda.Stream(dev, priority=pu)
         torch.cuda.synchronize(dev)
         B, L = data.shape[0], self.ae.latent_dim
         self.z_next = torch.zeros(B, L, device=dev)
@@ -235,9 +238,16 @@ class DDPMTrainer:
         with torch.cuda.graph(self.gE):
             self.z_out = self.encode(self.static_data)
         ops.set_workspace_slot(old)
+        # the denoiser shares the chip with the encoder stream: optionally capture it with a lower split-K threshold
+        # (fewer dependent launches; FL_PIPE_SPLITK_TILES, experiment knob)
+        import os as _os
+        skt = _os.environ.get("FL_PIPE_SPLITK_TILES")
+        old_skt = ops.set_gemm_splitk_tiles(int(skt)) if skt is not None else None
         self.gU = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gU):
             self.fwd_bwd(self.z_in, self.lab_in)
+        if old_skt is not None:
+            ops.set_gemm_splitk_tiles(old_skt)
         self.gO = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gO):
             self.update()
