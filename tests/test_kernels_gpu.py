@@ -48,6 +48,27 @@ def test_gemm_nt(dev, M, N, K):
     close(out, ref, tol=1e-5 * max(1, K ** 0.5 / 8))
 
 
+def test_gemm_splitk_policy(dev):
+    """fl_set_gemm_splitk_tiles only changes HOW a small-grid GEMM is spread over the chip (split along K + a reduce
+    launch, or not): the result is the same product up to fp32 summation order, the setting is restored by the caller."""
+    M, N, K = 256, 1024, 1024   # 4 x 16 tiles of 64 x 64: below the default threshold of 160 -> split-K by default
+    A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    ref = A.double() @ B.double().t() + bias.double()
+    outs = {}
+    old = ops.set_gemm_splitk_tiles(160)
+    try:
+        for tiles in (160, 16, 0):
+            assert ops.set_gemm_splitk_tiles(tiles) in (160, 16, 0)
+            outs[tiles] = ops.gemm(A.to(dev), B.to(dev), M, N, K, bias=bias.to(dev)).cpu()
+            close(outs[tiles], ref, tol=4e-5)
+    finally:
+        ops.set_gemm_splitk_tiles(old)
+    close(outs[0], outs[160], tol=4e-6)
+    with pytest.raises(RuntimeError):
+        ops.set_gemm_splitk_tiles(-1)
+    assert ops.set_gemm_splitk_tiles(old) == old
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 512, 256), (64, 102, 256), (8, 256, 512), (256, 1024, 1024), (37, 66, 40)])
 def test_linear_bwd(dev, M, N, K):
     x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(M, N, seed=3)
