@@ -66,10 +66,9 @@ def unet_fwd():
 
 def vaegan():
     torch.manual_seed(0)
-    from oracle import procedural_init as pinit  # synthetic VGG weights only (shape table), not a compute path
     ae = M.SimpleAutoencoder().to(dev).train()
     D = M.Discriminator64().to(dev).train()
-    vgg = M.VGGPerceptualLoss(dev, state_dict=pinit.procedural_state_dict(pinit.vgg16_features16_shapes(""), 7))
+    vgg = M.VGGPerceptualLoss(dev)  # seeded-synthetic weights (no network for the pretrained ones)
     tr = steps.VAEGANTrainer(ae, D, vgg, lr=1e-4)
     B = 64
     data = torch.empty(B, 3, 64, 64, device=dev); ops.philox_fill(data, 5, mode=2)
