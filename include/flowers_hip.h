@@ -214,6 +214,11 @@ int fl_axpby(float a, const float* x, float b, const float* y, float* out, int64
  * src/dst/n are HOST arrays. */
 int fl_multi_axpby(const void* const* src, void* const* dst, const int64_t* n, int entries, float a, float b,
                    fl_stream_t stream);
+/* out[i][c] = alpha[i] * sum_m x[i][m][c] for `entries` independent row-major [M][N] matrices in one launch (64 per
+ * launch): the bias gradients of the denoiser's nn.Linear layers (v2:1262), collected at the end of the backward.
+ * x/out/M/N/alpha are HOST arrays. */
+int fl_multi_colsum(const void* const* x, void* const* out, const int* M, const int* N, const float* alpha, int entries,
+                    fl_stream_t stream);
 /* attention-dropout of nn.MultiheadAttention on a length-1 sequence (v2:514,550-551) */
 int fl_scale_heads(const float* v, const float* head_mask, float* out, int B, int D, int heads, fl_stream_t stream);
 int fl_add_rows(const float* x, const float* y, int y_rows, float* out, int B, int D, fl_stream_t stream);

@@ -83,6 +83,34 @@ __global__ void multi_axpby_kernel(const MultiAxpby t, int entries, float a, flo
     if (i < n) y[i] = b != 0.f ? a * x[i] + b * y[i] : a * x[i];
   }
 }
+// Column sums of many [M][N] matrices in ONE launch (the bias gradients of every nn.Linear of the denoiser's backward:
+// 27 launches of ~5 us each otherwise, and each of them a link in the step's dependent chain). One block = 64 columns
+// of one matrix: 4 row groups x 64 lanes, combined through LDS in a fixed order.
+constexpr int FL_MCS_MAX = 64;
+struct MultiColsum {
+  const float* x[FL_MCS_MAX];
+  float* out[FL_MCS_MAX];
+  int blk0[FL_MCS_MAX + 1];
+  int M[FL_MCS_MAX], N[FL_MCS_MAX];
+  float alpha[FL_MCS_MAX];
+};
+__global__ __launch_bounds__(256) void multi_colsum_kernel(const MultiColsum t, int entries) {
+  __shared__ float part[4][64];
+  int lo = 0, hi = entries - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (t.blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int N = t.N[lo], M = t.M[lo];
+  const int c = (blockIdx.x - t.blk0[lo]) * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const float* __restrict__ x = t.x[lo];
+  float s = 0.f;
+  if (c < N)
+    for (int m = rg; m < M; m += 4) s += x[(long long)m * N + c];
+  part[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < N) t.out[lo][c] = t.alpha[lo] * (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]);
+}
 // out[b, c] = v[b, c] * hm[b, c / (D/heads)]   (attention-dropout on a length-1 sequence, v2:514)
 __global__ void scale_heads_kernel(const float* __restrict__ v, const float* __restrict__ hm, float* __restrict__ out,
                                    int B, int D, int heads) {
@@ -383,6 +411,29 @@ int fl_multi_axpby(const void* const* src, void* const* dst, const int64_t* n, i
     hipLaunchKernelGGL(multi_axpby_kernel, dim3(blocks), dim3(256), 0, ST(stream), t, cnt, a, b);
   }
   return fl::check_launch("multi_axpby");
+}
+int fl_multi_colsum(const void* const* x, void* const* out, const int* M, const int* N, const float* alpha, int entries,
+                    fl_stream_t stream) {
+  FL_REQUIRE(entries >= 0 && (entries == 0 || (x && out && M && N && alpha)), "fl_multi_colsum: bad args");
+  for (int e0 = 0; e0 < entries; e0 += FL_MCS_MAX) {
+    MultiColsum t;
+    const int cnt = entries - e0 < FL_MCS_MAX ? entries - e0 : FL_MCS_MAX;
+    int blocks = 0;
+    for (int i = 0; i < cnt; ++i) {
+      FL_REQUIRE(x[e0 + i] && out[e0 + i] && M[e0 + i] >= 0 && N[e0 + i] >= 0, "fl_multi_colsum: bad entry %d", e0 + i);
+      t.x[i] = reinterpret_cast<const float*>(x[e0 + i]);
+      t.out[i] = reinterpret_cast<float*>(out[e0 + i]);
+      t.M[i] = M[e0 + i];
+      t.N[i] = N[e0 + i];
+      t.alpha[i] = alpha[e0 + i];
+      t.blk0[i] = blocks;
+      blocks += (N[e0 + i] + 63) / 64;
+    }
+    t.blk0[cnt] = blocks;
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(multi_colsum_kernel, dim3(blocks), dim3(256), 0, ST(stream), t, cnt);
+  }
+  return fl::check_launch("multi_colsum");
 }
 int fl_scale_heads(const float* v, const float* head_mask, float* out, int B, int D, int heads, fl_stream_t stream) {
   FL_REQUIRE(heads > 0 && D % heads == 0, "fl_scale_heads: bad heads");

@@ -236,8 +236,15 @@ def unet_backward(un, S, dout, need_dx=False, gout=None):
     def wgrad(name, dy, x):
         G[name] = ops.linear_wgrad(dy, x, out=go(name))
 
-    def bgrad(name, dy, alpha=1.0):
-        G[name] = ops.colsum(dy, out=go(name), alpha=alpha)
+    pending = []  # bias gradients = column sums of the layer's dy: all of them in ONE launch at the end (the tensors
+    #               stay alive in this list), instead of 27 links in the dependent kernel chain of the step
+
+    def bgrad(name, dy, alpha=1.0, out=None):
+        out = out if out is not None else go(name)
+        if out is None:
+            out = ops.new((dy.shape[1],), dy)
+        pending.append((dy, out, alpha))
+        G[name] = out
 
     rw = _d(un.residual_weight).view(1)
     Wf = _d(un.final.weight)
@@ -285,7 +292,7 @@ def unet_backward(un, S, dout, need_dx=False, gout=None):
             gw = torch.zeros_like(att.in_proj_weight)
             gb = torch.zeros_like(att.in_proj_bias)
         ops.linear_wgrad(dv, hn, out=gw[2 * d:])
-        ops.colsum(dv, out=gb[2 * d:])
+        pending.append((dv, gb[2 * d:], 1.0))
         G[ap + "in_proj_weight"], G[ap + "in_proj_bias"] = gw, gb
         dhn = ops.linear_dgrad(dv, _d(att.in_proj_weight)[2 * d:])
         dh2, G[pre + "1.weight"], G[pre + "1.bias"] = ops.layernorm_bwd(
@@ -330,4 +337,5 @@ def unet_backward(un, S, dout, need_dx=False, gout=None):
         demb = ops.linear_dgrad(d1, _d(cm.lin1.weight))
         G["class_emb.embedding.weight"] = ops.embedding_bwd(demb, S.c, cm.embedding.weight.shape[0],
                                                             out=go("class_emb.embedding.weight"))
+    ops.multi_colsum(pending)
     return G, dx

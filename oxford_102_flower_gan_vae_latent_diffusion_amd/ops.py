@@ -493,6 +493,24 @@ def multi_axpby(pairs, a=1.0, b=0.0):
     _lib.call("fl_multi_axpby", src, dst, n, k, float(a), float(b), _stream())
 
 
+def multi_colsum(items):
+    """items: [(x (M,N), out (N,), alpha)] -> out = alpha * x.sum(0) for every item, in one launch per 64 items."""
+    items = [it for it in items if it[0].numel() > 0]
+    if not items:
+        return
+    k = len(items)
+    for x, out, _ in items:
+        _chk(x, out)
+        if x.dim() != 2 or out.numel() != x.shape[1]:
+            raise ValueError("multi_colsum: x must be (M,N) and out (N,), got %s / %s" % (tuple(x.shape), tuple(out.shape)))
+    xs = (ctypes.c_void_p * k)(*[x.data_ptr() for x, _, _ in items])
+    outs = (ctypes.c_void_p * k)(*[o.data_ptr() for _, o, _ in items])
+    Ms = (ctypes.c_int * k)(*[x.shape[0] for x, _, _ in items])
+    Ns = (ctypes.c_int * k)(*[x.shape[1] for x, _, _ in items])
+    al = (ctypes.c_float * k)(*[float(a) for _, _, a in items])
+    _lib.call("fl_multi_colsum", xs, outs, Ms, Ns, al, k, _stream())
+
+
 def scale_heads(v, head_mask, heads, out=None):
     _chk(v, head_mask, out)
     B, D = v.shape

@@ -48,6 +48,23 @@ def test_gemm_nt(dev, M, N, K):
     close(out, ref, tol=1e-5 * max(1, K ** 0.5 / 8))
 
 
+def test_multi_colsum(dev):
+    """bias gradients of many layers in one launch: out_i = alpha_i * x_i.sum(0), incl. ragged widths and a view output."""
+    shapes = [(256, 1024), (256, 256), (7, 102), (1, 64), (300, 33), (256, 1536)] + [(64, 96)] * 70   # > 64 entries: 2 launches
+    xs = [rnd(M, N, seed=10 + i) for i, (M, N) in enumerate(shapes)]
+    alphas = [1.0, 2.0, 0.5, 1.0, -1.0, 1.0] + [1.0] * 70
+    big = torch.zeros(4096, device=dev)
+    outs = [torch.empty(N, device=dev) for (_, N) in shapes]
+    outs[1] = big[512:768]                                                      # a slice of a flat gradient buffer
+    ops.multi_colsum([(x.to(dev), o, a) for x, o, a in zip(xs, outs, alphas)])
+    for x, o, a in zip(xs, outs, alphas):
+        close(o, a * x.double().sum(0), tol=2e-6 * max(1.0, x.shape[0] ** 0.5))
+    assert float(big[:512].abs().max()) == 0.0 and float(big[768:].abs().max()) == 0.0
+    ops.multi_colsum([])                                                        # nothing to do
+    with pytest.raises(ValueError):
+        ops.multi_colsum([(xs[0].to(dev), torch.empty(5, device=dev), 1.0)])
+
+
 def test_gemm_splitk_policy(dev):
     """fl_set_gemm_splitk_tiles only changes HOW a small-grid GEMM is spread over the chip (split along K + a reduce
     launch, or not): the result is the same product up to fp32 summation order, the setting is restored by the caller."""
