@@ -279,7 +279,7 @@ def test_batchnorm_synchronised_shards(dev, B, C, H, W, shards):
     close(db_sum, bg.grad, tol=5e-5)
 
 
-@pytest.mark.parametrize("rows,D", [(8, 256), (256, 1024), (4, 32768), (3, 512)])
+@pytest.mark.parametrize("rows,D", [(8, 256), (256, 1024), (4, 32768), (3, 512), (1000, 96), (2048, 128)])  # last: > 1024 rows = two-launch dw/db path
 def test_layernorm(dev, rows, D):
     x = rnd(rows, D, seed=1) * 2 + 0.3
     w, b, dy = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3), rnd(rows, D, seed=4)
