@@ -276,6 +276,8 @@ int fl_cross_entropy_bwd(const float* probs, const int64_t* labels, float gscale
                          int B, int C, fl_stream_t stream);
 /* y = softmax(scale*x) per row: attention weights of UNetAttentionBlock (v2:452-454) */
 int fl_softmax_rows(const float* x, float* y, int rows, int D, float scale, fl_stream_t stream);
+/* dx = scale * y * (dy - sum_j dy_j y_j): backward of the row softmax above (y = its output) */
+int fl_softmax_rows_bwd(const float* y, const float* dy, float* dx, int rows, int D, float scale, fl_stream_t stream);
 int fl_gather_rows(const float* table, const int64_t* idx, float* out, int B, int D, fl_stream_t stream); /* v2:363 */
 int fl_update_centers(float* centers, const float* z, const int64_t* labels, float momentum, int B, int D, int classes,
                       fl_stream_t stream);                                                            /* v2:369-378 */

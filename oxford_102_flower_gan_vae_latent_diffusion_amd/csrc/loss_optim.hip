@@ -217,6 +217,19 @@ __global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restri
   for (int i = threadIdx.x; i < D; i += blockDim.x) y[r * D + i] = expf(xr[i] * scale - mx) * inv;
 }
 
+// backward of y = softmax(scale*x) per row: dx = scale * y * (dy - sum_j dy_j y_j)   (UNetAttentionBlock training)
+__global__ void softmax_rows_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
+                                        int D, float scale) {
+  __shared__ float red[8];
+  const long long r = blockIdx.x;
+  const float* yr = y + r * D;
+  const float* gr = dy + r * D;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) s += gr[i] * yr[i];
+  s = fl::block_sum(s, red);
+  for (int i = threadIdx.x; i < D; i += blockDim.x) dx[r * D + i] = scale * yr[i] * (gr[i] - s);
+}
+
 // gather rows: out[b,:] = table[idx[b],:]
 __global__ void gather_rows_kernel(const float* __restrict__ table, const long long* __restrict__ idx,
                                    float* __restrict__ out, int B, int D) {
@@ -351,6 +364,12 @@ int fl_cross_entropy_bwd(const float* probs, const int64_t* labels, float gscale
   if (!n) return FL_OK;
   hipLaunchKernelGGL(ce_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), probs, (const long long*)labels, gscale, gdev, dlogits, B, C);
   return fl::check_launch("cross_entropy_bwd");
+}
+int fl_softmax_rows_bwd(const float* y, const float* dy, float* dx, int rows, int D, float scale, fl_stream_t stream) {
+  FL_REQUIRE(y && dy && dx && D > 0, "fl_softmax_rows_bwd: bad args");
+  if (rows == 0) return FL_OK;
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(rows), dim3(D >= 256 ? 256 : 64), 0, ST(stream), y, dy, dx, D, scale);
+  return fl::check_launch("softmax_rows_bwd");
 }
 int fl_softmax_rows(const float* x, float* y, int rows, int D, float scale, fl_stream_t stream) {
   if (!rows) return FL_OK;

@@ -93,9 +93,19 @@ def get_gemm_math():
 
 
 def gemm(A, B, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, bias=None, bias_scale=1.0, R=None,
-         r_scale=1.0, r_pre=False, act=ACT_NONE, act_param=0.0, out=None):
-    """C[m,n] = epi(sum_k A(m,k) B(n,k)); see flowers_hip.h fl_gemm_f32."""
+         r_scale=1.0, r_pre=False, act=ACT_NONE, act_param=0.0, out=None, ldc=None):
+    """C[m,n] = epi(sum_k A(m,k) B(n,k)); see flowers_hip.h fl_gemm_f32. ldc: row stride of `out` when it is a
+    column block of a wider matrix (out is then any tensor whose data_ptr is C[0,0]; no residual R)."""
     _chk(A, B, bias, R, out)
+    if ldc is not None:
+        if out is None or R is not None:
+            raise ValueError("gemm: ldc needs an explicit out and no residual")
+        need = _lib.load().fl_gemm_workspace_bytes(M, N, K)
+        wsp, wsn = _ws(min(need, 256 << 20), A)
+        _lib.call("fl_gemm_f32", _p(A), lda if lda is not None else (K if a_layout == KC else M), a_layout, _p(B),
+                  ldb if ldb is not None else (K if b_layout == KC else N), b_layout, _p(out), int(ldc), M, N, K, _p(bias),
+                  float(bias_scale), None, N, float(r_scale), int(r_pre), act, float(act_param), wsp, wsn, _stream())
+        return out
     if lda is None:
         lda = K if a_layout == KC else M
     if ldb is None:
@@ -706,6 +716,14 @@ def softmax_rows(x, scale=1.0):
     return y
 
 
+def softmax_rows_bwd(y, dy, scale=1.0):
+    _chk(y, dy)
+    rows, D = y.shape
+    dx = torch.empty_like(y)
+    _lib.call("fl_softmax_rows_bwd", _p(y), _p(dy), _p(dx), rows, D, float(scale), _stream())
+    return dx
+
+
 def gather_rows(table, idx):
     _chk(table, idx)
     out = new((idx.shape[0], table.shape[1]), table)
@@ -784,6 +802,16 @@ def chan_dot(dy, x):
     out = new((B, C), x)
     wsp, wsn = _norm_ws(B, H * W, C, x)
     _lib.call("fl_chan_sums", _p(x), _p(dy), None, _p(out), B, H * W, C, wsp, wsn, _stream())
+    return out
+
+
+def chan_sum(dy):
+    """(B,C): sum over pixels of dy (NHWC) - gradient of a per-(image, channel) bias broadcast over the map."""
+    _chk(dy)
+    B, H, W, C = dy.shape
+    out = new((B, C), dy)
+    wsp, wsn = _norm_ws(B, H * W, C, dy)
+    _lib.call("fl_chan_sums", _p(dy), None, _p(out), None, B, H * W, C, wsp, wsn, _stream())
     return out
 
 

@@ -48,6 +48,27 @@ def test_gemm_nt(dev, M, N, K):
     close(out, ref, tol=1e-5 * max(1, K ** 0.5 / 8))
 
 
+def test_softmax_rows_bwd_chan_sum_and_strided_gemm_output(dev):
+    """small pieces of the attention / residual-block backward: softmax', per-(image, channel) pixel sums, and a GEMM
+    that writes a column block of a wider matrix (ldc)."""
+    x = rnd(37, 64, seed=1)
+    dy = rnd(37, 64, seed=2)
+    xg = x.double().requires_grad_(True)
+    y = torch.softmax(0.3 * xg, dim=-1)
+    (y * dy.double()).sum().backward()
+    yd = ops.softmax_rows(x.to(dev), 0.3)
+    close(yd, y, tol=2e-6)
+    close(ops.softmax_rows_bwd(yd, dy.to(dev), 0.3), xg.grad, tol=2e-6)
+    g = rnd(3, 16, 5, 7, seed=3)
+    close(ops.chan_sum(nhwc(g).to(dev)), g.double().sum((2, 3)), tol=1e-5)
+    A, B = rnd(48, 40, seed=4), rnd(24, 40, seed=5)
+    wide = torch.full((48, 100), 7.0, device=dev)
+    ops.gemm(A.to(dev), B.to(dev), 48, 24, 40, out=wide.view(-1)[30:], ldc=100)
+    ref = torch.full((48, 100), 7.0, dtype=torch.float64)
+    ref[:, 30:54] = A.double() @ B.double().t()
+    close(wide, ref, tol=1e-5)
+
+
 def test_multi_colsum(dev):
     """bias gradients of many layers in one launch: out_i = alpha_i * x_i.sum(0), incl. ragged widths and a view output."""
     shapes = [(256, 1024), (256, 256), (7, 102), (1, 64), (300, 33), (256, 1536)] + [(64, 96)] * 70   # > 64 entries: 2 launches

@@ -269,6 +269,70 @@ def test_dead_conv_unet_blocks_vs_reference(dev):
         close(seq(x, t, c), f["seq"], 1e-4, "SwitchSequential")
 
 
+def test_conv_unet_blocks_backward_vs_oracle_autograd(dev):
+    """A18 as a trainable denoiser: gradients of the hand-written backward chains (attention: dV = P^T dO,
+    dS = softmax', dQ, dK; residual block: both LayerNorm2d, the broadcast time / class embeddings, dropout mask, 1x1
+    skip) against torch autograd on the oracle restatement (pinned by the reference's golden vectors), through a
+    SwitchSequential of three blocks and through each block alone."""
+    from oracle import v2_oracle as O
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import unet_blocks as U
+    f = load("dead_blocks")
+    x0, t0, c0 = f["x"][:2], f["t"][:2], f["c"][:2]
+    g = torch.Generator().manual_seed(3)
+
+    def run_ref(fn, sd, ins):
+        sd64 = {k: v.detach().double().requires_grad_(True) for k, v in sd.items()}
+        ins64 = [None if i is None else i.detach().double().requires_grad_(i.is_floating_point()) for i in ins]
+        out = fn(sd64, *ins64)
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(11), dtype=torch.float64)
+        (out * w).sum().backward()
+        return out.detach(), sd64, ins64, w
+
+    def run_dev(mod, ins, w):
+        mod = mod.to(dev)
+        mod.zero_grad()
+        insd = [None if i is None else i.detach().to(dev).requires_grad_(True) for i in ins]
+        out = mod(*insd)
+        (out * w.float().to(dev)).sum().backward()
+        return out.detach(), insd
+
+    def check(mod, fn, ins, what, tol=2e-4):
+        sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+        ref_out, sd64, ins64, w = run_ref(fn, sd, ins)
+        out, insd = run_dev(mod, ins, w)
+        close(out, ref_out, 1e-4, what + " output")
+        for (n, p) in mod.named_parameters():
+            if sd64[n].grad is None:            # unused in this call (class_emb without a class input): no gradient either side
+                assert p.grad is None, what + ": unexpected gradient for " + n
+                continue
+            close(p.grad, sd64[n].grad, tol, what + " d" + n)
+        for i, (a, b) in enumerate(zip(insd, ins64)):
+            if a is not None and a.grad is not None:   # the dropout mask is a constant of the step: no gradient
+                close(a.grad, b.grad, tol, what + " d(input %d)" % i)
+
+    attn = seeded(U.UNetAttentionBlock(64, num_heads=4), 45).train()
+    check(attn, lambda sd, x: O.unet_attention_block(sd, "", x), [x0], "attention block")
+    rb1 = seeded(U.UNetResidualBlock(64, 128, d_time=256, dropout_rate=0.2), 46).train()
+    mask = (torch.rand(2, 128, 8, 8, generator=g) > 0.2).float() / 0.8
+    check(rb1, lambda sd, x, t, c, m: O.unet_residual_block(sd, "", x, t, c, m), [x0, t0, c0, mask], "residual block 64->128")
+    rb2 = seeded(U.UNetResidualBlock(128, 128, d_time=256, dropout_rate=0.0), 47).train()
+    x1 = torch.randn(2, 128, 8, 8, generator=g)
+    check(rb2, lambda sd, x, t: O.unet_residual_block(sd, "", x, t), [x1, t0], "residual block 128 (identity skip, no class)")
+    # a chain of blocks trains end to end: SwitchSequential(res, attn, res), eval-mode dropout
+    rb1e = seeded(U.UNetResidualBlock(64, 128, d_time=256, dropout_rate=0.2), 46).eval()
+    attn2 = seeded(U.UNetAttentionBlock(128, num_heads=4), 48).eval()
+    rb2e = seeded(U.UNetResidualBlock(128, 128, d_time=256), 47).eval()
+    seq = U.SwitchSequential(rb1e, attn2, rb2e)
+
+    def seq_ref(sd, x, t, c):
+        sub = lambda i: {k[len("%d." % i):]: v for k, v in sd.items() if k.startswith("%d." % i)}
+        h = O.unet_residual_block(sub(0), "", x, t, c)
+        h = O.unet_attention_block(sub(1), "", h)
+        return O.unet_residual_block(sub(2), "", h, t, c)
+
+    check(seq, seq_ref, [x0, t0, c0], "SwitchSequential", tol=5e-4)
+
+
 def test_resume_is_bit_exact_and_loss_decreases(dev, tmp_path):
     """ reference-format checkpoint + side-car train state: a resumed run continues bit-exactly.
     Also a sanity check of the whole training path: the loss goes down on a fixed synthetic batch."""
