@@ -432,7 +432,21 @@ class ConditionalUNet(nn.Module):
         return f
 
     def dropout_masks(self, B, device):
-        """Philox dropout-scale tensors for train mode: (block_masks, head_masks)."""
+        """Philox dropout-scale tensors for train mode: (block_masks, head_masks). With one dropout rate everywhere (the
+        reference's dropout_rate feeds both nn.Dropout and the attention dropout, v2:503-516) all eight masks are slices of
+        ONE draw: 2 launches instead of 16 in the step's dependent kernel chain; elements stay independent (counter-based)."""
+        dims = [block[0].weight.shape[0] for block, _, _ in self.layers]
+        heads = [self.attention_layers[i].num_heads for i in range(len(self.layers))]
+        rates = {block[2].p for block, _, _ in self.layers} | {self.attention_layers[i].dropout for i in range(len(self.layers))}
+        if len(rates) == 1:
+            sizes = [B * d for d in dims] + [B * h for h in heads]
+            flat = self.rng.dropout((sum(sizes),), device, rates.pop())
+            parts, o = [], 0
+            for n in sizes:
+                parts.append(flat[o:o + n])
+                o += n
+            L = len(dims)
+            return ([parts[i].view(B, dims[i]) for i in range(L)], [parts[L + i].view(B, heads[i]) for i in range(L)])
         bm, hm = [], []
         for i, (block, _, _) in enumerate(self.layers):
             d = block[0].weight.shape[0]
