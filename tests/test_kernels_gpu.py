@@ -558,7 +558,9 @@ def test_conv_fwd_both_gemm_math_modes(dev, each_gemm_math):
                                                  # two whole 8x8 images per tile, tiles below the top image row, 4 N-tiles
                                                  (4, 512, 512, 8, 3, 1, 1), (3, 128, 256, 32, 3, 1, 1), (2, 256, 128, 16, 3, 1, 1),
                                                  # 4x4 s2 p1 halo kernel: 16-wide outputs, and four 8x8 output images (two per tile)
-                                                 (2, 128, 256, 32, 4, 2, 1), (4, 256, 512, 16, 4, 2, 1)])
+                                                 (2, 128, 256, 32, 4, 2, 1), (4, 256, 512, 16, 4, 2, 1),
+                                                 # grids that are not a multiple of the 8 XCDs (10 and 6 blocks), three N-tiles
+                                                 (5, 128, 128, 16, 3, 1, 1), (1, 256, 384, 16, 3, 1, 1), (6, 64, 128, 16, 4, 2, 1)])
 def test_conv_fwd_presplit_weight(dev, B, Cin, Cout, HW, k, s, p):
     """pre-split weight fragments (B_FRAGS) give the same convolution as the in-kernel split and as fp64 F.conv2d,
     with and without the fused LayerNorm2d statistics."""
