@@ -74,6 +74,13 @@ int fl_get_gemm_math(void);
  * results are the same up to fp32 summation order. Process-wide, read at launch time. */
 int fl_set_gemm_splitk_tiles(int tiles);
 int fl_get_gemm_splitk_tiles(void);
+/* Variant of the 3x3 halo-tile conv kernel behind fl_conv2d_fwd_presplit. 0 (default): 4 waves with 64x64 wave tiles,
+ * ~220 VGPRs, two blocks per CU - fastest on an otherwise idle chip. 1: 8 waves with 32x64 wave tiles, ~160 VGPRs, one
+ * block per CU - the same two conv waves per SIMD, but registers and LDS are left for the waves of a concurrently running
+ * stream (the denoiser next to the frozen encoder in the pipelined DDPM step). Same results up to fp32 summation order
+ * of the fused LayerNorm2d statistics (32- instead of 64-row slabs). Process-wide, read at launch time. */
+int fl_set_conv_halo_mode(int mode);
+int fl_get_conv_halo_mode(void);
 int fl_gemm_f32(const float* A, int64_t lda, int a_layout,
                 const float* B, int64_t ldb, int b_layout,
                 float* C, int64_t ldc, int M, int N, int K,

@@ -59,22 +59,27 @@ struct HaloArgs {
 constexpr int LROW = 36;  // floats per staged pixel: 32 channels + 4 pad (conflict-free ds_read_b128 over consecutive pixels)
 
 // dynamic LDS of conv3x3_halo_kernel<W> (must mirror the constants inside the kernel)
-constexpr int halo3_lds_bytes(int W) {
+constexpr int halo3_lds_bytes(int W) {  // independent of TM
   const int R = 128 / W, RI = R < W ? R : W, NI = R / RI, HR = RI + 2, HC = W + 2;
   const int RPAD = W == 32 ? 0 : ((W - HC) * LROW % 64 + 64) % 64;
   return 2 * NI * HR * (HC * LROW + RPAD) * 4;
 }
 
-template <int W>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) {
-  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WM = 64, WN = 64;
+// TM = 2: 4 waves (2 x 2), wave tile 64 x 64, ~220 VGPRs, 2 blocks per CU - the fastest on an otherwise idle chip.
+// TM = 1: 8 waves (4 x 2), wave tile 32 x 64, ~160 VGPRs, 1 block per CU - the same 2 waves per SIMD, but ~190 VGPRs
+// per SIMD and > 90 KB of LDS stay free, so the waves of a concurrently running stream (the denoiser's small dependent
+// kernels in the pipelined DDPM step) can start NEXT to the conv waves instead of waiting for a conv block to retire.
+template <int W, int TM>
+__global__ __launch_bounds__(TM == 2 ? 256 : 512, TM == 2 ? 2 : 1) void conv3x3_halo_kernel(const HaloArgs g) {
+  constexpr int BM = 128, BN = 128, TN = 2, WM = 32 * TM, WN = 64;
+  constexpr int NT = 64 * (BM / WM) * 2;    // threads per block
   constexpr int R = BM / W;                 // output rows per tile
   constexpr int RI = R < W ? R : W;         // ... per image
   constexpr int NI = R / RI;                // images per tile (2 for 8x8)
   constexpr int HR = RI + 2, HC = W + 2;    // halo rows / cols per image
   constexpr int P = NI * HR * HC;           // staged pixels
   constexpr int ITEMS = P * 8;              // float4 per chunk
-  constexpr int NST = (ITEMS + 255) / 256;  // float4 per thread per chunk
+  constexpr int NST = (ITEMS + NT - 1) / NT;  // float4 per thread per chunk
   // halo row pitch (floats). The 32 lanes of a fragment read are 32 consecutive output pixels; for W < 32 they span several
   // output rows, and the jump between rows must look like "the next W pixels" to the LDS banks (64 x 4 B), i.e.
   // RP == W * LROW (mod 64): then every lane hits the banks it would hit in the conflict-free W = 32 case (PMC: 46-63 %
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) 
   unsigned vmask = 0u;
 #pragma unroll
   for (int j = 0; j < NST; ++j) {
-    const int i = tid + 256 * j;
+    const int i = tid + NT * j;
     const int pix = i >> 3, c4 = i & 7;
     const int nl = pix / (HR * HC), rem = pix - nl * (HR * HC);
     const int hy = rem / HC, hx = rem - hy * HC;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) 
     float* dst = smem + buf * TILE_F;
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
-      if ((j + 1) * 256 > ITEMS && tid + 256 * j >= ITEMS) continue;  // only the last pass can run past the halo
+      if ((j + 1) * NT > ITEMS && tid + NT * j >= ITEMS) continue;  // only the last pass can run past the halo
       const bool ok = (vmask >> j) & 1u;
       float4 v = stg[j];
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;  // padding ring
@@ -305,9 +310,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const HaloArgs g) 
 // stores visible); the next chunk's global loads are still in flight under the whole chunk.
 constexpr int LROW2 = 20;
 
-template <int WO>
-__global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g) {
-  constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WM = 64, WN = 64;
+template <int WO, int TM>  // TM as in conv3x3_halo_kernel: 2 = 4 waves x (64 x 64), 1 = 8 waves x (32 x 64), one block per CU
+__global__ __launch_bounds__(TM == 2 ? 256 : 512, TM == 2 ? 2 : 1) void conv4x4s2_halo_kernel(const HaloArgs g) {
+  constexpr int BM = 128, BN = 128, TN = 2, WM = 32 * TM, WN = 64;
+  constexpr int NT = 64 * (BM / WM) * 2;      // threads per block
   constexpr int W = 2 * WO;                   // input height = width
   constexpr int R = BM / WO;                  // output rows per tile
   constexpr int RI = R < WO ? R : WO;         // ... per image
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g
   constexpr int HR = 2 * RI + 2, HC = 2 * WO + 2;
   constexpr int P = NI * HR * HC;
   constexpr int ITEMS = P * 4;                // float4 per 16-channel chunk
-  constexpr int NST = (ITEMS + 255) / 256;
+  constexpr int NST = (ITEMS + NT - 1) / NT;
   // LDS image: even and odd input columns in separate planes, so that the 32 lanes of a fragment read (32 consecutive
   // output pixels = input columns 2 ox + dx) are CONSECUTIVE pixels of one plane: pitch 20 floats = an odd multiple of
   // 4 banks -> 16 lanes cover the 64 banks exactly once. Row pitch RP2 makes the jump to the next output row (two
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g
   unsigned vmask = 0u;
 #pragma unroll
   for (int j = 0; j < NST; ++j) {
-    const int i = tid + 256 * j;
+    const int i = tid + NT * j;
     const int pix = i >> 2, c4 = i & 3;
     const int nl = pix / (HR * HC), rem = pix - nl * (HR * HC);
     const int hy = rem / HC, hx = rem - hy * HC;
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_halo_kernel(const HaloArgs g
   auto stage_store = [&]() {
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
-      if ((j + 1) * 256 > ITEMS && tid + 256 * j >= ITEMS) continue;
+      if ((j + 1) * NT > ITEMS && tid + NT * j >= ITEMS) continue;
       const bool ok = (vmask >> j) & 1u;
       float4 v = stg[j];
       v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
@@ -535,11 +541,15 @@ bool conv3x3_halo_applicable(const float* x, int B, int H, int W, int Cin, int C
 // 3x3 s1 p1 (W in 8/16/32) or 4x4 s2 p1 (input W in 16/32/64); the caller checked conv3x3_halo_applicable
 int launch_conv3x3_halo(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int B, int H, int W,
                         int Cin, int Cout, int act, float act_param, hipStream_t s) {
-  return launch_conv_halo(x, wsplit, bias, y, stats, B, H, W, Cin, Cout, 3, act, act_param, s);
+  return launch_conv_halo(x, wsplit, bias, y, stats, B, H, W, Cin, Cout, 3, act, act_param, 64, s);
 }
 
+// rows per statistics slab (= rows of a wave tile) the halo kernels use in `mode` (0: 64-row wave tiles, 1: the
+// co-residency-friendly 32-row ones)
+int conv_halo_slab_rows(int ksize, int mode) { return (mode == 2 || (mode == 1 && ksize == 3)) ? 32 : 64; }  // 1: 3x3 only, 2: both
+
 int launch_conv_halo(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int B, int H, int W,
-                     int Cin, int Cout, int ksize, int act, float act_param, hipStream_t s) {
+                     int Cin, int Cout, int ksize, int act, float act_param, int slab_rows, hipStream_t s) {
   HaloArgs g;
   g.x = x; g.wsplit = reinterpret_cast<const u32x4_t*>(wsplit); g.bias = bias; g.y = y; g.stats = stats;
   g.Cin = Cin; g.Cout = Cout; g.tiles_n = Cout / 128; g.act = act; g.act_param = act_param;
@@ -548,20 +558,35 @@ int launch_conv_halo(const float* x, const void* wsplit, const float* bias, floa
     const int blocks = (g.M / 128) * g.tiles_n;
     static std::once_flag once;
     std::call_once(once, [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(32));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(16));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(8));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(32));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(16));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(8));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(32));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(16));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, halo3_lds_bytes(8));
     });
-    if (W == 32) hipLaunchKernelGGL(conv3x3_halo_kernel<32>, dim3(blocks), dim3(256), halo3_lds_bytes(32), s, g);
-    else if (W == 16) hipLaunchKernelGGL(conv3x3_halo_kernel<16>, dim3(blocks), dim3(256), halo3_lds_bytes(16), s, g);
-    else hipLaunchKernelGGL(conv3x3_halo_kernel<8>, dim3(blocks), dim3(256), halo3_lds_bytes(8), s, g);
+    if (slab_rows == 32) {
+      if (W == 32) hipLaunchKernelGGL((conv3x3_halo_kernel<32, 1>), dim3(blocks), dim3(512), halo3_lds_bytes(32), s, g);
+      else if (W == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<16, 1>), dim3(blocks), dim3(512), halo3_lds_bytes(16), s, g);
+      else hipLaunchKernelGGL((conv3x3_halo_kernel<8, 1>), dim3(blocks), dim3(512), halo3_lds_bytes(8), s, g);
+    } else {
+      if (W == 32) hipLaunchKernelGGL((conv3x3_halo_kernel<32, 2>), dim3(blocks), dim3(256), halo3_lds_bytes(32), s, g);
+      else if (W == 16) hipLaunchKernelGGL((conv3x3_halo_kernel<16, 2>), dim3(blocks), dim3(256), halo3_lds_bytes(16), s, g);
+      else hipLaunchKernelGGL((conv3x3_halo_kernel<8, 2>), dim3(blocks), dim3(256), halo3_lds_bytes(8), s, g);
+    }
   } else {
     const int Wo = W / 2;
     g.M = B * Wo * Wo;
     const int blocks = (g.M / 128) * g.tiles_n;
-    if (Wo == 32) hipLaunchKernelGGL(conv4x4s2_halo_kernel<32>, dim3(blocks), dim3(256), 0, s, g);
-    else if (Wo == 16) hipLaunchKernelGGL(conv4x4s2_halo_kernel<16>, dim3(blocks), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(conv4x4s2_halo_kernel<8>, dim3(blocks), dim3(256), 0, s, g);
+    if (slab_rows == 32) {
+      if (Wo == 32) hipLaunchKernelGGL((conv4x4s2_halo_kernel<32, 1>), dim3(blocks), dim3(512), 0, s, g);
+      else if (Wo == 16) hipLaunchKernelGGL((conv4x4s2_halo_kernel<16, 1>), dim3(blocks), dim3(512), 0, s, g);
+      else hipLaunchKernelGGL((conv4x4s2_halo_kernel<8, 1>), dim3(blocks), dim3(512), 0, s, g);
+    } else {
+      if (Wo == 32) hipLaunchKernelGGL((conv4x4s2_halo_kernel<32, 2>), dim3(blocks), dim3(256), 0, s, g);
+      else if (Wo == 16) hipLaunchKernelGGL((conv4x4s2_halo_kernel<16, 2>), dim3(blocks), dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((conv4x4s2_halo_kernel<8, 2>), dim3(blocks), dim3(256), 0, s, g);
+    }
   }
   return fl::check_launch("conv_halo_kernel");
 }

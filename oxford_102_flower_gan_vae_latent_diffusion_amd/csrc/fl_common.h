@@ -91,6 +91,7 @@ bool conv3x3_halo_applicable(const float* x, int B, int H, int W, int Cin, int C
 int launch_conv3x3_halo(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int B, int H, int W,
                         int Cin, int Cout, int act, float act_param, hipStream_t s);
 int launch_conv_halo(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int B, int H, int W,
-                     int Cin, int Cout, int ksize, int act, float act_param, hipStream_t s);
+                     int Cin, int Cout, int ksize, int act, float act_param, int slab_rows, hipStream_t s);
+int conv_halo_slab_rows(int ksize, int mode);
 
 }  // namespace fl

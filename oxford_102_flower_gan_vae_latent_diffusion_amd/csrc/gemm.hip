@@ -901,6 +901,9 @@ int launch_cfg(GArgs g, int classes, hipStream_t stream) {
 // chip). A caller whose GEMMs share the chip with another stream (the denoiser next to the frozen encoder) lowers it:
 // there the extra reduce launch costs more than the idle CUs it would fill (fl_set_gemm_splitk_tiles).
 int g_splitk_tiles = 160;
+// 3x3 halo conv variant: 0 = 4 waves x (64 x 64) tiles, 2 blocks per CU (fastest alone); 1 = 8 waves x (32 x 64) tiles,
+// 1 block per CU with VGPRs / LDS left for another stream's waves (fl_set_conv_halo_mode)
+int g_conv_halo_mode = 0;
 
 template <int AM, int BMODE>
 int launch_gemm(GArgs g, int classes, void* ws, size_t ws_bytes, hipStream_t stream, int* wm_out = nullptr) {
@@ -1062,12 +1065,13 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // 3x3 s1 p1 / 4x4 s2 p1 on the encoder's square maps: the halo-tile kernels stage each channel chunk once for all taps
   static const bool halo_on = !(getenv("FL_CONV_HALO") && getenv("FL_CONV_HALO")[0] == '0');
-  const int rc = (halo_on && fl::conv3x3_halo_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad))
-                     ? fl::launch_conv_halo(x, wsplit, bias, y, g.stats, B, H, W, Cin, Cout, kh, act, act_param, s)
-                     : launch_cfg3<128, 128, 2, 2, A_KC_CONV, B_FRAGS, 2, 6>(g, 1, s);
+  const bool halo = halo_on && fl::conv3x3_halo_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad);
+  const int slab = halo ? fl::conv_halo_slab_rows(kh, g_conv_halo_mode) : 64;  // rows per statistics slab
+  const int rc = halo ? fl::launch_conv_halo(x, wsplit, bias, y, g.stats, B, H, W, Cin, Cout, kh, act, act_param, slab, s)
+                      : launch_cfg3<128, 128, 2, 2, A_KC_CONV, B_FRAGS, 2, 6>(g, 1, s);
   if (rc || !stats) return rc;
   hipLaunchKernelGGL(conv_inorm_finalize, dim3(fl::cdiv((long long)B * Cout, 256)), dim3(256), 0, s, g.stats, ln_w, ln_b, eps,
-                     scale, shift, mean, rstd, B, HW, Cout, HW / 64);
+                     scale, shift, mean, rstd, B, HW, Cout, HW / slab);
   return fl::check_launch("conv_inorm_finalize");
 }
 
@@ -1084,6 +1088,13 @@ int fl_set_gemm_splitk_tiles(int tiles) {
   return FL_OK;
 }
 int fl_get_gemm_splitk_tiles(void) { return g_splitk_tiles; }
+
+int fl_set_conv_halo_mode(int mode) {
+  FL_REQUIRE(mode >= 0 && mode <= 2, "fl_set_conv_halo_mode: mode %d (0 = 64x64 wave tiles, 1 = 32x64 for the 3x3 convs, 2 = 32x64 for all)", mode);
+  g_conv_halo_mode = mode;
+  return FL_OK;
+}
+int fl_get_conv_halo_mode(void) { return g_conv_halo_mode; }
 
 size_t fl_conv2d_fwd_instnorm_workspace_bytes(int B, int Ho, int Wo, int Cout) {
   return ((size_t)B * Ho * Wo / 32 + 1) * 2 * (size_t)Cout * sizeof(float);

@@ -88,6 +88,15 @@ def set_gemm_splitk_tiles(tiles):
     return old
 
 
+def set_conv_halo_mode(mode):
+    """Variant of the 3x3 halo conv kernel of the pre-split path: 0 = 64x64 wave tiles, two blocks per CU (fastest
+    alone); 1 = 32x64 wave tiles, one 8-wave block per CU, leaving registers / LDS for a concurrent stream's waves.
+    Returns the previous mode."""
+    old = int(_lib.load().fl_get_conv_halo_mode())
+    _lib.call("fl_set_conv_halo_mode", int(mode))
+    return old
+
+
 def get_gemm_math():
     return "split" if _lib.load().fl_get_gemm_math() else "fp32"
 

@@ -8,6 +8,8 @@ Every host sync of the reference (.item(), clip_grad_norm_) is removed: losses, 
 scales, step count and lr stay on the device. Data-parallel runs add ONE RCCL all-reduce of the flat gradient
 buffer per step; the ddpm step can be replayed as hipGraphs.
 """
+import os
+
 import torch
 
 from . import engine, engine_bwd, ops
@@ -234,9 +236,14 @@ class DDPMTrainer:
         old = ops.set_workspace_slot(1)           # encoder graph: its own scratch (runs concurrently with U)
         self.encode(data)                         # size slot-1 workspace outside capture
         torch.cuda.synchronize(dev)
+        # the encoder graph runs NEXT to the denoiser graph: capture its 3x3 convs in the variant that leaves registers and
+        # LDS for the other stream's waves (FL_PIPE_HALO_MODE=0 keeps the stand-alone-fastest variant)
+        halo_mode = int(os.environ.get("FL_PIPE_HALO_MODE", "1"))
+        old_mode = ops.set_conv_halo_mode(halo_mode)
         self.gE = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gE):
             self.z_out = self.encode(self.static_data)
+        ops.set_conv_halo_mode(old_mode)
         ops.set_workspace_slot(old)
         # the denoiser shares the chip with the encoder stream: optionally capture it with a lower split-K threshold
         # (fewer dependent launches; FL_PIPE_SPLITK_TILES, experiment knob)

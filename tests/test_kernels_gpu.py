@@ -552,6 +552,13 @@ def test_conv_fwd_both_gemm_math_modes(dev, each_gemm_math):
     close(outs["split"], outs["fp32"].cpu(), tol=2e-6)
 
 
+@pytest.fixture(params=[0, 1])
+def halo_mode(request):
+    old = ops.set_conv_halo_mode(request.param)
+    yield request.param
+    ops.set_conv_halo_mode(old)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,HW,k,s,p", [(2, 128, 128, 32, 3, 1, 1), (3, 64, 128, 64, 4, 2, 1), (1, 256, 256, 16, 3, 1, 1),
                                                  (2, 256, 512, 16, 4, 2, 1),
                                                  # 3x3 s1 p1 on 8/16/32-wide maps -> halo-tile kernel (conv_halo.hip):
@@ -561,9 +568,9 @@ def test_conv_fwd_both_gemm_math_modes(dev, each_gemm_math):
                                                  (2, 128, 256, 32, 4, 2, 1), (4, 256, 512, 16, 4, 2, 1),
                                                  # grids that are not a multiple of the 8 XCDs (10 and 6 blocks), three N-tiles
                                                  (5, 128, 128, 16, 3, 1, 1), (1, 256, 384, 16, 3, 1, 1), (6, 64, 128, 16, 4, 2, 1)])
-def test_conv_fwd_presplit_weight(dev, B, Cin, Cout, HW, k, s, p):
+def test_conv_fwd_presplit_weight(dev, B, Cin, Cout, HW, k, s, p, halo_mode):
     """pre-split weight fragments (B_FRAGS) give the same convolution as the in-kernel split and as fp64 F.conv2d,
-    with and without the fused LayerNorm2d statistics."""
+    with and without the fused LayerNorm2d statistics; both variants of the 3x3 halo kernel (fl_set_conv_halo_mode)."""
     x = rnd(B, Cin, HW, HW, seed=1)
     w = rnd(Cout, Cin, k, k, seed=2, scale=0.05)
     bias = rnd(Cout, seed=3)
