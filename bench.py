@@ -43,7 +43,7 @@ def conv_shapes(B):
     return s
 
 
-def measure_dominant_kernel(dev, B, reps=5):
+def measure_dominant_kernel(dev, B, reps=5, halo_mode=0):
     """HIP-event timing (on the stream the kernels are launched on = torch's current stream) of every conv launch of the
     frozen encoder in one step, grouped by the kernel that serves it -> average duration per launch and algorithmic
     TFLOP/s per kernel. In split mode the six 3x3 ResidualBlock convs run on conv3x3_halo_kernel (the dominant kernel
@@ -51,6 +51,7 @@ def measure_dominant_kernel(dev, B, reps=5):
     from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
     groups = {}
     halo_on = os.environ.get("FL_CONV_HALO", "1") != "0"
+    old_mode = ops.set_conv_halo_mode(halo_mode)  # the instantiation the timed step runs (pipelined step: mode 1)
     for name, b, H, W, Ci, Co, k, s, p in conv_shapes(B):
         x = torch.empty(b, H, W, Ci, device=dev)
         ops.philox_fill(x, seed=11, mode=0)
@@ -87,6 +88,7 @@ def measure_dominant_kernel(dev, B, reps=5):
         gr["by"] += by
         gr["n"] += 1
         gr["per"].append((name, ms, fl / ms / 1e9))
+    ops.set_conv_halo_mode(old_mode)
     res = {}
     for kname, gr in groups.items():
         res[kname] = dict(avg_ms=gr["t"] / gr["n"], tflops=gr["f"] / gr["t"] / 1e9, flop_per_launch=gr["f"] / gr["n"],
@@ -282,7 +284,8 @@ def main():
     }
     if rank == 0 and world == 1:
         if not a.no_roofline:
-            groups = measure_dominant_kernel(dev, B)
+            pipe_mode = int(os.environ.get("FL_PIPE_HALO_MODE", "1")) if overlap else 0
+            groups = measure_dominant_kernel(dev, B, halo_mode=pipe_mode)
             dom = max(groups, key=lambda kname: groups[kname]["total_ms"])
             r = groups[dom]
             log("dominant kernel (%s): %.1f TFLOP/s avg over %d launches" % (dom, r["tflops"], r["launches"]))
@@ -292,8 +295,9 @@ def main():
             peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PIECE_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS
             math_note = ("6 x v_mfma_f32_32x32x16_bf16 per 16 k on exact bf16 pieces of the fp32 operands" if split
                          else "v_mfma_f32_32x32x2_f32")
-            names = {"halo": "conv3x3_halo_kernel<W> (3x3 s1 p1 conv of the encoder's ResidualBlocks: input halo staged once "
-                             "per 32-channel chunk, weights pre-split, " + math_note + ")",
+            v3 = "1: 8 waves x 32x64 tiles, leaves VGPRs/LDS for the denoiser stream" if pipe_mode in (1, 2) else "2: 4 waves x 64x64 tiles"
+            names = {"halo": "conv3x3_halo_kernel<W," + v3 + "> (3x3 s1 p1 conv of the encoder's ResidualBlocks: input halo "
+                             "staged once per 32-channel chunk, weights pre-split, " + math_note + ")",
                      "halo_s2": "conv4x4s2_halo_kernel<Wo> (4x4 s2 p1 down-sampling convs: input halo staged once per 16-channel "
                                 "chunk, weights pre-split, " + math_note + ")",
                      "gemm": ("gemm_kernel<128,128,2,2,A_KC_CONV,B_FRAGS> (implicit-GEMM conv, weights pre-split, " if split
