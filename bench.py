@@ -62,13 +62,20 @@ def measure_dominant_kernel(dev, B, reps=5, halo_mode=0):
         y = torch.empty(b, Ho, Ho, Co, device=dev)
         # the launch the step itself makes: in split mode the frozen encoder's weights are pre-split (B_FRAGS operand)
         presplit = ops.get_gemm_math() == "split" and ops.presplit_ok(Ci, Co, Ho * Ho)
-        if presplit:
+        h2 = presplit and os.environ.get("FL_CONV_F16X2", "1") != "0" and ops.f16x2_ok(x, Co, k, k, s, p)
+        if h2:  # f16x2 split math (csrc/conv_h2.hip): what engine.conv_ln_infer launches for the ResidualBlock convs
+            wh2, geom = ops.pack_weight_f16x2(w), tuple(w.shape)
+            amax = torch.full((1,), 8.0, device=dev)  # range information: philox_fill mode 0 (normal) draws are bounded by 8
+            run = lambda: ops.conv2d_fwd_f16x2(x, wh2, geom, bias, s, p, out=y, x_amax=amax)
+        elif presplit:
             wsp, geom = ops.split_pack_weight(w), tuple(w.shape)
             run = lambda: ops.conv2d_fwd_presplit(x, wsp, geom, bias, s, p, out=y)
         else:
             run = lambda: ops.conv2d_fwd(x, w, bias, s, p, out=y)
         kern = "gemm"
-        if presplit and halo_on and k == 3 and s == 1 and H in (8, 16, 32):
+        if h2:
+            kern = "h2"
+        elif presplit and halo_on and k == 3 and s == 1 and H in (8, 16, 32):
             kern = "halo"
         elif presplit and halo_on and k == 4 and s == 2 and H in (16, 32, 64):
             kern = "halo_s2"
@@ -82,7 +89,8 @@ def measure_dominant_kernel(dev, B, reps=5, halo_mode=0):
         ms = e0.elapsed_time(e1) / reps
         fl = 2.0 * b * Ho * Ho * Co * k * k * Ci
         by = 4.0 * b * (H * H * Ci + Ho * Ho * Co) + (6.0 if presplit else 4.0) * Co * k * k * Ci  # x + y + weights, once
-        gr = groups.setdefault(kern, dict(t=0.0, f=0.0, by=0.0, n=0, per=[]))
+        gr_pp = 3 if h2 else (SPLIT_PIECE_PRODUCTS if ops.get_gemm_math() == "split" else 0)
+        gr = groups.setdefault(kern, dict(t=0.0, f=0.0, by=0.0, n=0, per=[], pp=gr_pp))
         gr["t"] += ms
         gr["f"] += fl
         gr["by"] += by
@@ -92,7 +100,7 @@ def measure_dominant_kernel(dev, B, reps=5, halo_mode=0):
     res = {}
     for kname, gr in groups.items():
         res[kname] = dict(avg_ms=gr["t"] / gr["n"], tflops=gr["f"] / gr["t"] / 1e9, flop_per_launch=gr["f"] / gr["n"],
-                          bytes_per_launch=gr["by"] / gr["n"], launches=gr["n"], total_ms=gr["t"], per=gr["per"])
+                          bytes_per_launch=gr["by"] / gr["n"], launches=gr["n"], total_ms=gr["t"], per=gr["per"], pp=gr["pp"])
     return res
 
 
@@ -292,11 +300,16 @@ def main():
             split = gemm_math == "split"
             # the fraction is taken against the peak of the instruction the kernel actually issues: in split mode one
             # algorithmic fp32 flop costs SPLIT_PIECE_PRODUCTS bf16 flops, so the ceiling of the scheme is 2500/6 TFLOP/s
-            peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PIECE_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS
+            def peak_of(gr):  # ceiling of the scheme the kernel issues: 16-bit dense MFMA peak / piece products per fp32 product
+                return BF16_MFMA_PEAK_TFLOPS / gr["pp"] if gr["pp"] else FP32_MFMA_PEAK_TFLOPS
+            peak = peak_of(r)
             math_note = ("6 x v_mfma_f32_32x32x16_bf16 per 16 k on exact bf16 pieces of the fp32 operands" if split
                          else "v_mfma_f32_32x32x2_f32")
             v3 = "1: 8 waves x 32x64 tiles, leaves VGPRs/LDS for the denoiser stream" if pipe_mode in (1, 2) else "2: 4 waves x 64x64 tiles"
-            names = {"halo": "conv3x3_halo_kernel<W," + v3 + "> (3x3 s1 p1 conv of the encoder's ResidualBlocks: input halo "
+            names = {"h2": "conv3x3_h2_kernel<W> (3x3 s1 p1 conv of the encoder's ResidualBlocks in f16x2 split math: operands scaled by "
+                           "a power of two and split into 2 fp16 pieces, 3 x v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulation; halo "
+                           "split once per 16-channel chunk at LDS staging, pre-split weights via LDS-DMA ring)",
+                     "halo": "conv3x3_halo_kernel<W," + v3 + "> (3x3 s1 p1 conv of the encoder's ResidualBlocks: input halo "
                              "staged once per 32-channel chunk, weights pre-split, " + math_note + ")",
                      "halo_s2": "conv4x4s2_halo_kernel<Wo> (4x4 s2 p1 down-sampling convs: input halo staged once per 16-channel "
                                 "chunk, weights pre-split, " + math_note + ")",
@@ -304,7 +317,7 @@ def main():
                               else "gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> (implicit-GEMM conv, ") + math_note + ")"}
             # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, averaged over the kernel's
             # launches at B=256; profiles/r01_conv_kernel_pmc.md). Not re-measured live: PMC needs the profiler.
-            traffic = {"halo": PMC_TRAFFIC_HALO, "halo_s2": None, "gemm": 4.4e8 if split else 4.08e8}[dom] if B == 256 else None
+            traffic = {"h2": None, "halo": PMC_TRAFFIC_HALO, "halo_s2": None, "gemm": 4.4e8 if split else 4.08e8}[dom] if B == 256 else None
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": names[dom],
@@ -312,8 +325,8 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": r["tflops"] / peak,
-                "peak_basis": ("bf16 dense MFMA peak %.0f / %d piece products per fp32 product" % (BF16_MFMA_PEAK_TFLOPS, SPLIT_PIECE_PRODUCTS))
-                              if split else "fp32 dense MFMA peak",
+                "peak_basis": ("16-bit dense MFMA peak %.0f / %d piece products per fp32 product" % (BF16_MFMA_PEAK_TFLOPS, r["pp"]))
+                              if r["pp"] else "fp32 dense MFMA peak",
                 "achieved_over_fp32_mfma_peak": r["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                 "split_vs_fp32_mfma_max_rel_diff": split_vs_fp32_mfma(dev),
                 "traffic": traffic,
@@ -321,7 +334,7 @@ def main():
                 "avg_launch_ms": r["avg_ms"],
                 "algorithmic_gflop_per_launch": r["flop_per_launch"] / 1e9,
                 "launches_per_step": r["launches"],
-                "other_conv_kernels": {names[kname]: {"achieved": g2["tflops"], "frac": g2["tflops"] / peak,
+                "other_conv_kernels": {names[kname]: {"achieved": g2["tflops"], "frac": g2["tflops"] / peak_of(g2),
                                                       "avg_launch_ms": g2["avg_ms"], "launches_per_step": g2["launches"]}
                                        for kname, g2 in groups.items() if kname != dom},
                 "all_encoder_convs_tflops": sum(g2["flop_per_launch"] * g2["launches"] for g2 in groups.values())

@@ -116,6 +116,23 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
                            int Cout, int kh, int kw, int stride, int pad, int act, float act_param, const float* ln_w,
                            const float* ln_b, float eps, float* scale, float* shift, float* mean, float* rstd, void* ws,
                            size_t ws_bytes, fl_stream_t stream);
+/* 3x3 / stride 1 / pad 1 forward conv in "f16x2" split math (csrc/conv_h2.hip; the ResidualBlock convs of the frozen
+ * encoder, v2:159-178). Every fp32 operand is scaled by a power of two and split by round-to-nearest into two fp16
+ * pieces x*2^e = h + l (+ <= 2^-22 |x| 2^e); a product is 3 of the 4 piece products on v_mfma_f32_32x32x16_f16 (piece
+ * products exact, fp32 accumulation): fp32-equivalent accuracy (measured better than the native fp32 MFMA) at half
+ * the matrix instructions of the bf16x3 scheme. fl_pack_weight_f16x2 scales (per tensor, amax -> [2^14,2^15)), splits
+ * and lays out the packed weight [Cout][kh*kw*Cin] once (fl_pack_weight_f16x2_bytes(N,K) = 256 + 4*N*K bytes).
+ * Activations are scaled by 2^x_exp, or - when x_amax != NULL - by the power of two that maps *x_amax (a device float
+ * >= max|x|, kept by the kernel that produced x) into [2^14,2^15). |x| 2^e >= 65520 yields NaN outputs (loud).
+ * Needs H == W in {8,16,32}, Cin % 32 == 0, Cout % 128 == 0, B*H*W % 256 == 0 (fl_conv2d_fwd_f16x2_applicable).
+ * scale != NULL adds the fused LayerNorm2d statistics of fl_conv2d_fwd_instnorm (same outputs and workspace). */
+size_t fl_pack_weight_f16x2_bytes(int N, int K);
+int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, fl_stream_t stream);
+int fl_conv2d_fwd_f16x2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+int fl_conv2d_fwd_f16x2(const float* x, const void* wpack, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
+                        int kh, int kw, int stride, int pad, int act, float act_param, const float* ln_w, const float* ln_b,
+                        float eps, float* scale, float* shift, float* mean, float* rstd, const float* x_amax, int x_exp,
+                        void* ws, size_t ws_bytes, fl_stream_t stream);
 /* dx = conv_transpose(dy, w): input gradient of the conv above (stride 1 any
  * kernel; stride 2 only for 4x4 p1).  dy:(B,Ho,Wo,Cout) -> dx:(B,H,W,Cin).
  * wp is the SAME packed weight as the forward. */
@@ -159,6 +176,11 @@ int fl_batchnorm_stats(const float* x, const float* w, const float* b, float eps
                        int HW, int C, void* ws, size_t ws_bytes, fl_stream_t stream);
 int fl_affine_act(const float* x, const float* scale, const float* shift, int per_image, const float* R, float* y, int B,
                   int HW, int C, int act, float act_param, fl_stream_t stream);
+/* out[0] = mult * max|w| + max|b| (+ prev[0] when prev != NULL; w NULL = 1, b NULL = 0): a rigorous bound on the
+ * magnitude of a LayerNorm2d / LayerNorm output (|x - mean| * rstd <= sqrt(n) = mult) after its affine map; Swish and
+ * gates in (0,1) only shrink it, a residual adds its own bound (prev). Computed once per weight version and handed to
+ * fl_conv2d_fwd_f16x2 as x_amax. */
+int fl_affine_bound(const float* w, const float* b, int C, float mult, const float* prev, float* out, fl_stream_t stream);
 /* backward of y = act(norm(x)); coef is scratch: 3*B*C floats (3*C for batch norm) */
 int fl_instnorm_bwd(const float* dy, const float* x, const float* scale, const float* shift, const float* w,
                     const float* mean, const float* rstd, int act, float act_param, float* dx, float* dw, float* db,

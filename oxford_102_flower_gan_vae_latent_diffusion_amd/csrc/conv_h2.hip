@@ -1,0 +1,450 @@
+// 3x3 / stride 1 / pad 1 convolution in "f16x2" split math: the ResidualBlock convs of the frozen encoder (v2:159-178),
+// the dominant kernel of the latent-DDPM step.
+//
+// Math. Every fp32 operand is scaled by a power of two (exact) and split into TWO fp16 pieces by round-to-nearest,
+//   X = x * 2^e,  h = f16(X),  l = f16(X - h)        (X - h is exact in fp32; |X - h - l| <= 2^-22 |X|, unbiased)
+// and a product is assembled from 3 of the 4 piece products (l*h, h*l, h*h - smallest first) on
+// v_mfma_f32_32x32x16_f16: an f16 x f16 product is exact in fp32, accumulation is the fp32 accumulation of the MFMA. The
+// dropped l*l term is <= 2^-22 |xy|. Measured against fp64 this is MORE accurate than the native fp32 MFMA and than the
+// 6-product bf16x3 scheme of gemm.hip (tests/test_kernels_gpu.py::test_f16x2_conv_is_fp32_equivalent), at 3 matrix
+// instructions per 16 k-values instead of 6. The power-of-two scales keep every piece inside fp16's exponent range:
+// weights are scaled per tensor at pack time (amax -> [2^14, 2^15), fl_pack_weight_f16x2), activations by 2^a_exp or
+// from a device-resident amax word kept by the producing kernel; values > 2^-17 amax keep both pieces in the normal
+// range, smaller ones lose at most 2^-40 amax. The epilogue undoes both scales exactly. |x| * 2^e >= 65520 gives inf
+// and then NaN in the output - loud, never silently wrong.
+//
+// Structure (MI355X: one 512-thread block per CU, 2 waves per SIMD):
+//   * block tile 256 output pixels x 128 output channels, wave tile 64 x 64 (2 x 2 MFMA tiles of 32 x 32);
+//   * A: the tile's input halo ((rows + 2) x (W + 2) pixels) of one 16-channel chunk is loaded ONCE per chunk as fp32,
+//     split ONCE by the staging thread into an h plane and an l plane of fp16 ([pixel][16 + 8 pad] halfs, double
+//     buffered) and all nine taps read their MFMA A fragments from it with one ds_read_b128 per (32 rows, plane) at a
+//     shifted address. (r01 kernel: the fp32 halo was re-split by every wave for every tap, 176 of ~210 VALU
+//     instructions per tap; here the inner loop has no VALU work besides addresses.)
+//   * B: the weights were split and laid out in MFMA-fragment order once (fl_pack_weight_f16x2); the 8 KB a block needs
+//     per (tap, chunk) go global -> LDS by LDS-DMA (global_load_lds_dwordx4, one per wave and tap) into a 3-slot ring,
+//     three taps ahead, and are shared by the four waves of a column (r01: every wave fetched its own copy from L2).
+//   * one s_barrier per tap (12 MFMAs per wave); fragments of tap t+1 are read under the MFMAs of tap t; LDS-DMA stays in
+//     flight across barriers (counted vmcnt, raw s_barrier).
+#include "fl_common.h"
+#include <mutex>
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int H2_HDR = 256;  // bytes in front of the weight fragments: [0] amax bits, [1] 2^-e_w (float)
+
+struct H2Args {
+  const float* x;
+  const char* wpack;
+  const float* bias;
+  float* y;
+  float* stats;
+  const unsigned* a_amax;  // optional device word: bits of a bound on max|x|; NULL -> a_exp
+  int a_exp;
+  int Cin, Cout, M, tiles_n, act;
+  float act_param;
+};
+
+__device__ __forceinline__ int scale_exp_from_amax(unsigned bits) {
+  const int E = (int)((bits >> 23) & 0xffu);
+  int e = E ? 141 - E : 0;  // amax * 2^e in [2^14, 2^15)
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return e;
+}
+
+template <int W>
+struct H2Geom {
+  static constexpr int BM = 256, BN = 128;
+  static constexpr int R = BM / W, RI = R < W ? R : W, NI = R / RI, HR = RI + 2, HC = W + 2;
+  static constexpr int PXB = 48;  // bytes per staged pixel and plane: 16 halfs + 8 pad (odd multiple of 16 B: conflict-free b128)
+  // row pitch: the 32 lanes of a fragment read are 32 consecutive output pixels; for W < 32 they span several rows and the
+  // jump to the next row must look like "the next W pixels" to the 64 banks: RPB == W * PXB (mod 256 B)
+  static constexpr int RPB = W == 32 ? HC * PXB : (W == 16 ? 1024 : 640);
+  static constexpr int PLANE_B = NI * HR * RPB, ABUF_B = 2 * PLANE_B;
+  static constexpr int NS = 3, SLOT_B = 8192, BOFF = 2 * ABUF_B;
+  static constexpr int LDS_B = BOFF + NS * SLOT_B;
+  static constexpr int P = NI * HR * HC, ITEMS = P * 4, NT = 512, NST = (ITEMS + NT - 1) / NT;
+  static_assert(RPB >= HC * PXB && (W == 32 || (RPB - W * PXB) % 256 == 0), "row pitch");
+  static_assert(LDS_B <= 160 * 1024, "LDS");
+};
+
+template <int W, int PRIO>
+__global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
+  using G = H2Geom<W>;
+  constexpr int BM = G::BM, BN = G::BN, RI = G::RI, HR = G::HR, HC = G::HC, PXB = G::PXB, RPB = G::RPB;
+  constexpr int PLANE_B = G::PLANE_B, ABUF_B = G::ABUF_B, BOFF = G::BOFF, SLOT_B = G::SLOT_B;
+  constexpr int ITEMS = G::ITEMS, NT = G::NT, NST = G::NST;
+  static_assert(NST == 3 || NST == 4, "staging passes");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile_m0 = (tile / g.tiles_n) * BM;
+  const int tile_n0 = (tile % g.tiles_n) * BN;
+  const int img0 = tile_m0 / (W * W);
+  const int oy0 = (tile_m0 - img0 * (W * W)) / W;
+  const int Cin = g.Cin, nC = Cin >> 4;  // 16-channel chunks
+
+  // ---- scales (powers of two, exact)
+  const int ea = g.a_amax ? scale_exp_from_amax(*g.a_amax) : g.a_exp;
+  const float sa = __uint_as_float((unsigned)(ea + 127) << 23);
+  const float out_scale = reinterpret_cast<const float*>(g.wpack)[1] * __uint_as_float((unsigned)(127 - ea) << 23);
+
+  // ---- staging descriptors: item i = tid + 512 j -> (halo pixel i >> 2, float4 i & 3); invariant over chunks
+  int goff[NST], sdst[NST];
+  unsigned vmask = 0u;
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const int i = tid + NT * j;
+    const int pix = i >> 2, c4 = i & 3;
+    const int nl = pix / (HR * HC), rem = pix - nl * (HR * HC);
+    const int hy = rem / HC, hx = rem - hy * HC;
+    const int iy = oy0 - 1 + hy, ix = hx - 1;
+    const bool ok = (i < ITEMS) && ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
+    goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
+    sdst[j] = (i < ITEMS) ? (nl * HR + hy) * RPB + hx * PXB + c4 * 8 : -1;
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+
+  // halo loads are inline asm: hipcc must not count them (beside LDS-DMA it would drain vmcnt to 0 at their first use);
+  // stage_wait() is the one place their registers become valid
+  f32x4v stg[NST];
+  auto stage_load = [&](int c) {
+    const float* xc = g.x + c * 16;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const float* p = xc + goff[j];
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg[j]) : "v"(p) : "memory");
+    }
+  };
+  // s_waitcnt vmcnt(N) that also pins the staging registers (N literal)
+#define FL_STAGE_WAIT(N)                                                                                         \
+  do {                                                                                                           \
+    if constexpr (NST == 3)                                                                                      \
+      asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2])::"memory");              \
+    else                                                                                                         \
+      asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[NST - 1])::"memory"); \
+  } while (0)
+  auto stage_store = [&](int buf) {
+    char* dst = smem + buf * ABUF_B;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      if (sdst[j] < 0) continue;
+      const bool ok = (vmask >> j) & 1u;
+      f16x4_t h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float X = ok ? stg[j][e] * sa : 0.f;
+        const _Float16 hh = (_Float16)X;
+        h[e] = hh;
+        l[e] = (_Float16)(X - (float)hh);
+      }
+      *reinterpret_cast<f16x4_t*>(dst + sdst[j]) = h;
+      *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = l;
+    }
+  };
+
+  // ---- A fragment addresses (bytes inside a plane): tile row r -> halo pixel of tap (0,0); tap (dy,dx) adds dy*RPB + dx*PXB
+  int abase[2];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int r = wr * 64 + tm * 32 + li;
+    const int nl = r / (RI * W), rr = r - nl * (RI * W);
+    const int oyl = rr / W, ox = rr - oyl * W;
+    abase[tm] = (nl * HR + oyl) * RPB + ox * PXB + 16 * lh;
+  }
+  const int bfrag = BOFF + wc * 4096 + lane * 16;  // + slot * 8192 + tn * 2048 + piece * 1024
+
+  // ---- B ring: tap (c, t) -> global fragments [g16 = t * nC + c][32-col tile][piece][lane] x 16 B; this wave moves the
+  // wid-th KB of the tap's 8 KB
+  const int nt32 = g.Cout >> 5;
+  const char* wsrc = g.wpack + H2_HDR + ((size_t)(tile_n0 >> 5) * 128 + wid * 64 + lane) * 16;
+  const size_t g16_stride = (size_t)nt32 * 128 * 16;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto dma_tap = [&](int c, int t, int slot) {
+    const int cc = c < nC ? c : nC - 1;  // past the end: a harmless reload into a slot nobody reads
+    const char* src = wsrc + (size_t)(t * nC + cc) * g16_stride;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + BOFF + slot * SLOT_B + wid * 1024), 16, 0, 0);
+  };
+
+  struct Frags {
+    f16x8_t a[2][2];  // [tm][plane]
+    f16x8_t b[2][2];  // [tn][piece]
+  };
+  auto frag_load = [&](Frags& f, int abuf, int tapoff, int slot) {
+    const char* A = smem + abuf * ABUF_B + tapoff;
+    const char* Bp = smem + bfrag + slot * SLOT_B;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) f.b[tn][p] = *reinterpret_cast<const f16x8_t*>(Bp + tn * 2048 + p * 1024);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) f.a[tm][p] = *reinterpret_cast<const f16x8_t*>(A + abase[tm] + p * PLANE_B);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  auto mfma12 = [&](const Frags& f) {
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#define FL_PIECE(pa, pb)                                                                         \
+    _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm][pa], f.b[tn][pb], acc[tm][tn], 0, 0, 0);
+    FL_PIECE(1, 0) FL_PIECE(0, 1) FL_PIECE(0, 0)  // l*h, h*l, h*h: smallest terms first
+#undef FL_PIECE
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: chunk 0 staged, taps 0..2 of chunk 0 in the ring, fragments of tap 0 in registers
+  stage_load(0);
+  dma_tap(0, 0, 0);
+  dma_tap(0, 1, 1);
+  dma_tap(0, 2, 2);
+  FL_STAGE_WAIT(3);
+  stage_store(0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  Frags fA, fB;
+  frag_load(fA, 0, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // one tap: DMA three taps ahead into the slot this tap's fragments came from, fragments of the next tap under this
+  // tap's MFMAs, then [counted vmcnt: the DMA of tap t+2 has landed] + lgkmcnt(0) + barrier
+  auto tap = [&](auto tap_c, Frags& cur, Frags& nxt, int c) {
+    constexpr int T = decltype(tap_c)::value;
+    constexpr int T3 = (T + 3) % 9, C3 = (T + 3) / 9;        // tap t+3
+    constexpr int T1 = (T + 1) % 9, C1 = (T + 1) / 9;        // tap t+1
+    dma_tap(c + C3, T3, T % 3);
+    if constexpr (T == 0) stage_load(c + 1 < nC ? c + 1 : c);
+    frag_load(nxt, (c + C1) & 1, (T1 / 3) * RPB + (T1 % 3) * PXB, T1 % 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma12(cur);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (T == 0 || T == 1) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST + 1) : "memory");
+    } else if constexpr (T == 2) {
+      FL_STAGE_WAIT(1);  // the halo loads of tap 0 are older than DMA(t+2): now complete
+    } else {
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    }
+    if constexpr (T == 3) stage_store((c + 1) & 1);  // the other buffer: last read while tap 7 of the previous chunk ran
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) as a builtin: hipcc then knows the fragment reads have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto chunk = [&](auto par, int c) {
+    constexpr int PAR = decltype(par)::value;  // which register set holds tap 0's fragments
+    Frags& f0 = PAR ? fB : fA;
+    Frags& f1 = PAR ? fA : fB;
+    tap(std::integral_constant<int, 0>{}, f0, f1, c);
+    tap(std::integral_constant<int, 1>{}, f1, f0, c);
+    tap(std::integral_constant<int, 2>{}, f0, f1, c);
+    tap(std::integral_constant<int, 3>{}, f1, f0, c);
+    tap(std::integral_constant<int, 4>{}, f0, f1, c);
+    tap(std::integral_constant<int, 5>{}, f1, f0, c);
+    tap(std::integral_constant<int, 6>{}, f0, f1, c);
+    tap(std::integral_constant<int, 7>{}, f1, f0, c);
+    tap(std::integral_constant<int, 8>{}, f0, f1, c);
+  };
+#pragma unroll 1
+  for (int c = 0; c < nC; c += 2) {  // nC is even (Cin % 32 == 0)
+    chunk(std::integral_constant<int, 0>{}, c);
+    chunk(std::integral_constant<int, 1>{}, c + 1);
+  }
+#undef FL_STAGE_WAIT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the block's LDS allocation
+
+  // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+  float st1[2], st2[2], bv[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    st1[tn] = st2[tn] = 0.f;
+    bv[tn] = g.bias ? g.bias[tile_n0 + wc * 64 + tn * 32 + li] : 0.f;
+  }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = tile_m0 + wr * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      float* yrow = g.y + (size_t)m * g.Cout + tile_n0 + wc * 64 + li;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const float v = fl::apply_act(acc[tm][tn][e] * out_scale + bv[tn], g.act, g.act_param);
+        yrow[tn * 32] = v;
+        st1[tn] += v;
+        st2[tn] += v * v;
+      }
+    }
+  }
+  // fused LayerNorm2d statistics: this wave's 64 rows lie in one image (H*W % 64 == 0): one slab of (sum y, sum y^2)
+  if (g.stats) {
+    const int grp = (tile_m0 + wr * 64) / 64;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const float a = st1[tn] + __shfl_xor(st1[tn], 32, 64);
+      const float b = st2[tn] + __shfl_xor(st2[tn], 32, 64);
+      const int col = tile_n0 + wc * 64 + tn * 32 + li;
+      if (lh == 0) {
+        g.stats[((size_t)grp * 2) * g.Cout + col] = a;
+        g.stats[((size_t)grp * 2 + 1) * g.Cout + col] = b;
+      }
+    }
+  }
+}
+
+// ---- weight pack: fp32 [N][K] -> header + [16-k group][32-col tile][piece h|l][lane][8 halfs]
+__global__ void h2_amax_kernel(const float* __restrict__ w, long long n, unsigned* hdr) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(w[i]));
+  m = fl::wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(hdr, __float_as_uint(m));  // non-negative floats order like their bits
+}
+
+__global__ void h2_pack_kernel(const float* __restrict__ w, char* __restrict__ out, int N, int K) {
+  const unsigned* hdr = reinterpret_cast<const unsigned*>(out);
+  const int e = scale_exp_from_amax(hdr[0]);
+  const float s = __uint_as_float((unsigned)(e + 127) << 23);
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) reinterpret_cast<float*>(out)[1] = __uint_as_float((unsigned)(127 - e) << 23);
+  const int nt = N >> 5;
+  if (i >= (long long)(K >> 4) * nt * 64) return;
+  const int lane = (int)(i & 63), lr = lane & 31, lh = lane >> 5;
+  const long long gt = i >> 6;
+  const int t = (int)(gt % nt);
+  const long long g16 = gt / nt;
+  const float* row = w + (long long)(32 * t + lr) * K + 16 * g16 + 8 * lh;  // k slots of this lane: 8*lh + j
+  const float4 q0 = *reinterpret_cast<const float4*>(row), q1 = *reinterpret_cast<const float4*>(row + 4);
+  const float x[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+  f16x8_t h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float X = x[j] * s;
+    const _Float16 hh = (_Float16)X;
+    h[j] = hh;
+    l[j] = (_Float16)(X - (float)hh);
+  }
+  f16x8_t* o = reinterpret_cast<f16x8_t*>(out + H2_HDR) + (gt * 2) * 64 + lane;
+  o[0] = h;
+  o[64] = l;
+}
+
+template <int W>
+void h2_set_attr() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, H2Geom<W>::LDS_B);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, H2Geom<W>::LDS_B);
+}
+
+}  // namespace
+
+namespace fl {
+
+bool conv3x3_h2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
+  if (Cin % 32 || Cout % 128 || (reinterpret_cast<uintptr_t>(x) & 15) || H != W) return false;
+  if ((long long)B * H * W * Cin >= (1ll << 31)) return false;
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && (W == 8 || W == 16 || W == 32)) return ((long long)B * H * W) % 256 == 0;
+  return false;
+}
+
+int launch_conv3x3_h2(const float* x, const void* wpack, const float* bias, float* y, float* stats, const unsigned* a_amax,
+                      int a_exp, int B, int H, int W, int Cin, int Cout, int act, float act_param, hipStream_t s) {
+  H2Args g;
+  g.x = x; g.wpack = reinterpret_cast<const char*>(wpack); g.bias = bias; g.y = y; g.stats = stats;
+  g.a_amax = a_amax; g.a_exp = a_exp;
+  g.Cin = Cin; g.Cout = Cout; g.tiles_n = Cout / 128; g.act = act; g.act_param = act_param;
+  g.M = B * H * W;
+  const int blocks = (g.M / 256) * g.tiles_n;
+  static std::once_flag once;
+  std::call_once(once, [] { h2_set_attr<32>(); h2_set_attr<16>(); h2_set_attr<8>(); });
+  static int prio = -1;
+  if (prio < 0) { const char* e = getenv("FL_H2_PRIO"); prio = e ? atoi(e) : 1; }
+#define FL_LAUNCH(WW)                                                                                              \
+  do {                                                                                                             \
+    if (prio) hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 1>), dim3(blocks), dim3(512), H2Geom<WW>::LDS_B, s, g);    \
+    else hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 0>), dim3(blocks), dim3(512), H2Geom<WW>::LDS_B, s, g);         \
+  } while (0)
+  if (W == 32) FL_LAUNCH(32);
+  else if (W == 16) FL_LAUNCH(16);
+  else FL_LAUNCH(8);
+#undef FL_LAUNCH
+  return fl::check_launch("conv3x3_h2_kernel");
+}
+
+size_t pack_weight_f16x2_bytes(int N, int K) { return (size_t)H2_HDR + (size_t)N * K * 4; }
+
+int pack_weight_f16x2(const float* w, void* out, int N, int K, hipStream_t s) {
+  if (hipMemsetAsync(out, 0, H2_HDR, s) != hipSuccess) return fl::check_launch("pack_weight_f16x2 memset");
+  const long long n = (long long)N * K;
+  int blocks = fl::cdiv(n, 256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(h2_amax_kernel, dim3(blocks), dim3(256), 0, s, w, n, reinterpret_cast<unsigned*>(out));
+  const long long total = (long long)(K / 16) * (N / 32) * 64;
+  hipLaunchKernelGGL(h2_pack_kernel, dim3(fl::cdiv(total, 256)), dim3(256), 0, s, w, reinterpret_cast<char*>(out), N, K);
+  return fl::check_launch("h2_pack_kernel");
+}
+
+}  // namespace fl
+
+// =====================================================================================
+extern "C" {
+
+size_t fl_pack_weight_f16x2_bytes(int N, int K) { return fl::pack_weight_f16x2_bytes(N, K); }
+
+// w: [N][K] fp32 (a packed conv weight [Cout][kh][kw][Cin]), N % 32 == 0, K % 16 == 0
+int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, fl_stream_t stream) {
+  FL_REQUIRE(w && out && N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, "fl_pack_weight_f16x2: N=%d (mult. of 32), K=%d (mult. of 16)", N, K);
+  FL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0, "fl_pack_weight_f16x2: 16-byte alignment");
+  return fl::pack_weight_f16x2(w, out, N, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+int fl_conv2d_fwd_f16x2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
+  return fl::conv3x3_h2_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad) ? 1 : 0;
+}
+
+int fl_conv2d_fwd_f16x2(const float* x, const void* wpack, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
+                        int kh, int kw, int stride, int pad, int act, float act_param, const float* ln_w, const float* ln_b,
+                        float eps, float* scale, float* shift, float* mean, float* rstd, const float* x_amax, int x_exp,
+                        void* ws, size_t ws_bytes, fl_stream_t stream) {
+  FL_REQUIRE(x && wpack && y, "fl_conv2d_fwd_f16x2: null operand");
+  FL_REQUIRE(fl::conv3x3_h2_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad),
+             "fl_conv2d_fwd_f16x2: unsupported shape (B=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d)", B, H, W, Cin, Cout, kh, kw, stride, pad);
+  FL_REQUIRE(x_exp >= -100 && x_exp <= 100, "fl_conv2d_fwd_f16x2: x_exp %d out of range", x_exp);
+  const int HW = H * W;
+  const bool stats = scale != nullptr;
+  if (stats) {
+    FL_REQUIRE(shift && act == FL_ACT_NONE && HW % 64 == 0, "fl_conv2d_fwd_f16x2: fused statistics need shift, act NONE, H*W %% 64 == 0");
+    FL_REQUIRE(ws && ws_bytes >= fl_conv2d_fwd_instnorm_workspace_bytes(B, H, W, Cout), "fl_conv2d_fwd_f16x2: workspace too small");
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  float* part = stats ? reinterpret_cast<float*>(ws) : nullptr;
+  const int rc = fl::launch_conv3x3_h2(x, wpack, bias, y, part, reinterpret_cast<const unsigned*>(x_amax), x_exp, B, H, W, Cin, Cout,
+                                       act, act_param, s);
+  if (rc || !stats) return rc;
+  return fl::launch_conv_inorm_finalize(part, ln_w, ln_b, eps, scale, shift, mean, rstd, B, HW, Cout, HW / 64, s);
+}
+
+}  // extern "C"

@@ -93,5 +93,14 @@ int launch_conv3x3_halo(const float* x, const void* wsplit, const float* bias, f
 int launch_conv_halo(const float* x, const void* wsplit, const float* bias, float* y, float* stats, int B, int H, int W,
                      int Cin, int Cout, int ksize, int act, float act_param, int slab_rows, hipStream_t s);
 int conv_halo_slab_rows(int ksize, int mode);
+int launch_conv_inorm_finalize(const float* partial, const float* ln_w, const float* ln_b, float eps, float* scale, float* shift,
+                               float* mean, float* rstd, int B, int HW, int C, int slabs, hipStream_t s);
+
+// f16x2 split math (conv_h2.hip): 3x3 s1 p1 conv, weights packed once (header + fp16 h|l fragments)
+bool conv3x3_h2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+int launch_conv3x3_h2(const float* x, const void* wpack, const float* bias, float* y, float* stats, const unsigned* a_amax,
+                      int a_exp, int B, int H, int W, int Cin, int Cout, int act, float act_param, hipStream_t s);
+size_t pack_weight_f16x2_bytes(int N, int K);
+int pack_weight_f16x2(const float* w, void* out, int N, int K, hipStream_t s);
 
 }  // namespace fl

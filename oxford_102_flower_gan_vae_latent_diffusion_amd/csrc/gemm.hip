@@ -1022,6 +1022,16 @@ __global__ void conv_inorm_finalize(const float* partial, const float* w, const 
 
 }  // namespace
 
+namespace fl {
+// per-(image, channel) LayerNorm2d scale/shift from a conv epilogue's statistics slabs (shared with conv_h2.hip)
+int launch_conv_inorm_finalize(const float* partial, const float* ln_w, const float* ln_b, float eps, float* scale, float* shift,
+                               float* mean, float* rstd, int B, int HW, int C, int slabs, hipStream_t s) {
+  hipLaunchKernelGGL(conv_inorm_finalize, dim3(fl::cdiv((long long)B * C, 256)), dim3(256), 0, s, partial, ln_w, ln_b, eps, scale,
+                     shift, mean, rstd, B, HW, C, slabs);
+  return fl::check_launch("conv_inorm_finalize");
+}
+}  // namespace fl
+
 // =====================================================================================
 extern "C" {
 

@@ -471,6 +471,21 @@ __global__ void layernorm_bwd_wb_partial(const float* __restrict__ dy, const flo
 
 }  // namespace
 
+namespace {
+// out[0] = mult * max|w| + max|b| (+ prev[0]): a rigorous bound on |w * n + b| for a normalised n with |n| <= mult
+__global__ void affine_bound_kernel(const float* w, const float* b, int C, float mult, const float* prev, float* out) {
+  __shared__ float red[8];
+  float mw = w ? 0.f : 1.f, mb = 0.f;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    if (w) mw = fmaxf(mw, fabsf(w[i]));
+    if (b) mb = fmaxf(mb, fabsf(b[i]));
+  }
+  mw = fl::block_max(mw, red);
+  mb = fl::block_max(mb, red);
+  if (threadIdx.x == 0) out[0] = mult * mw + mb + (prev ? prev[0] : 0.f);
+}
+}  // namespace
+
 extern "C" {
 
 size_t fl_norm_workspace_bytes(int B, int HW, int C) {
@@ -691,5 +706,12 @@ int fl_chan_sums(const float* x, const float* dy, float* out1, float* out2, int 
   if (rc) return rc;
   hipLaunchKernelGGL(chan_sums_finalize, dim3(fl::cdiv((long long)B * C, 256)), dim3(256), 0, st, partial, out1, out2, B, C, sl.S);
   return fl::check_launch("chan_sums_finalize");
+}
+// |LayerNorm-style affine output| <= mult * max|w| + max|b| + prev: with mult = sqrt(#elements normalised together) this
+// bounds LayerNorm2d / LayerNorm outputs (|x - mean| * rstd <= sqrt(n)); Swish and gates in (0,1) only shrink it.
+int fl_affine_bound(const float* w, const float* b, int C, float mult, const float* prev, float* out, fl_stream_t stream) {
+  FL_REQUIRE(out && C > 0 && mult >= 0.f, "fl_affine_bound: bad arguments");
+  hipLaunchKernelGGL(affine_bound_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, b, C, mult, prev, out);
+  return fl::check_launch("affine_bound_kernel");
 }
 }  // extern "C"

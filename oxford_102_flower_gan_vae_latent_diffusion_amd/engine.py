@@ -4,11 +4,15 @@ Everything here works on NHWC fp32 device tensors and on the *parameter containe
 modules.py (real nn.Conv2d / nn.Linear / ... objects whose .weight/.bias carry the reference's
 state-dict keys); no torch arithmetic is executed — only libflowers_hip.so kernels.
 """
+import os
+
 import torch
 
 from . import ops
 
 SW = ops.ACT_SWISH
+# f16x2 split math for the 3x3 ResidualBlock convs of the inference paths (FL_CONV_F16X2=0: the r01 bf16x3 kernels)
+USE_F16X2 = os.environ.get("FL_CONV_F16X2", "1") != "0"
 
 
 class PackCache:
@@ -46,16 +50,39 @@ class PackCache:
         return self.get(("convsplit", id(conv)), [w], make)
 
 
+    def conv_h2(self, conv):
+        """nn.Conv2d weight scaled, split into two fp16 pieces and laid out in MFMA-fragment order once
+        (ops.pack_weight_f16x2) for the f16x2 inference convs -> (pack, (O, kh, kw, Ipad))."""
+        w = conv.weight
+
+        def make():
+            wp = self.conv(conv)
+            return ops.pack_weight_f16x2(wp), tuple(wp.shape)
+
+        return self.get(("convh2", id(conv)), [w], make)
+
+    def ln_bound(self, ln, n, prev=None):
+        """(1,) device float bounding |ln(.)| (and what Swish / (0,1) gates make of it) for a norm over n elements, plus
+        the bound `prev` of a residual input: the range information of the f16x2 convs. Per weight version."""
+        return self.get(("lnbound", id(ln), n, id(prev)), [ln.weight, ln.bias],
+                        lambda: ops.affine_bound(ln.weight.detach(), ln.bias.detach(), float(n) ** 0.5, prev))
+
+
 def _d(p):
     return p.detach() if p is not None else None
 
 
-def conv_ln_infer(x, conv, ln, stride, pad, pk):
-    """inference conv + fused LayerNorm2d statistics -> (y, scale, shift); weights pre-split when the layer qualifies."""
+def conv_ln_infer(x, conv, ln, stride, pad, pk, x_bound=None):
+    """inference conv + fused LayerNorm2d statistics -> (y, scale, shift); weights pre-split when the layer qualifies.
+    x_bound: (1,) device float >= max|x| (PackCache.ln_bound) - enables the f16x2 kernel for the 3x3 convs."""
     B, H, W, Cin = x.shape
     Cout, _, kh, kw = conv.weight.shape
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-    if ops.get_gemm_math() == "split" and ops.presplit_ok(Cin, Cout, Ho * Wo):
+    if ops.get_gemm_math() == "split" and x_bound is not None and USE_F16X2 and ops.f16x2_ok(x, Cout, kh, kw, stride, pad):
+        wh, geom = pk.conv_h2(conv)
+        y, (sc, sh, _, _) = ops.conv2d_fwd_f16x2(x, wh, geom, _d(conv.bias), stride, pad, ln_w=_d(ln.weight), ln_b=_d(ln.bias),
+                                                 eps=ln.eps, x_amax=x_bound)
+    elif ops.get_gemm_math() == "split" and ops.presplit_ok(Cin, Cout, Ho * Wo):
         ws, geom = pk.conv_split(conv)
         y, (sc, sh, _, _) = ops.conv2d_fwd_presplit(x, ws, geom, _d(conv.bias), stride, pad, ln_w=_d(ln.weight),
                                                     ln_b=_d(ln.bias), eps=ln.eps)
@@ -74,11 +101,13 @@ def ca_gate(ca, pooled):
     return ops.linear(h, w2, None, act=ops.ACT_SIGMOID)
 
 
-def resblock_infer(x, rb, pk):
-    """ResidualBlock.forward (v2:170-178), NHWC, no saved state. 2 convs + 2 stats passes + 3 streaming passes."""
-    y1, sc, sh = conv_ln_infer(x, rb.conv1, rb.ln1, 1, 1, pk)
+def resblock_infer(x, rb, pk, x_bound=None):
+    """ResidualBlock.forward (v2:170-178), NHWC, no saved state. 2 convs + 2 stats passes + 3 streaming passes.
+    x_bound: (1,) device float >= max|x| or None (then the range-agnostic bf16x3 conv kernels run)."""
+    HW = x.shape[1] * x.shape[2]
+    y1, sc, sh = conv_ln_infer(x, rb.conv1, rb.ln1, 1, 1, pk, x_bound)
     a1 = ops.affine_act(y1, sc, sh, act=SW, out=y1)
-    y2, sc2, sh2 = conv_ln_infer(a1, rb.conv2, rb.ln2, 1, 1, pk)
+    y2, sc2, sh2 = conv_ln_infer(a1, rb.conv2, rb.ln2, 1, 1, pk, pk.ln_bound(rb.ln1, HW) if x_bound is not None else None)
     # avg_pool(LayerNorm2d(y)) == ln2.bias exactly (normalised maps have zero spatial mean), so the
     # channel-attention gate (v2:65-66) is one (C,) vector shared by the batch: no pooling pass.
     # ... and a function of the weights only: computed once per weight version, not per batch.
@@ -108,7 +137,7 @@ def encoder_infer(enc, x):
         dn, rb = getattr(enc, "down%d" % i), getattr(enc, "res%d" % i)
         y, sc, sh = conv_ln_infer(h, dn[0], dn[1], 2, 1, pk)
         h = ops.affine_act(y, sc, sh, act=SW, out=y)
-        h = resblock_infer(h, rb, pk)
+        h = resblock_infer(h, rb, pk, pk.ln_bound(dn[1], y.shape[1] * y.shape[2]))  # |swish(ln(.))| <= the ln bound
         feats.append(h)
     # x.view(B,-1) of the NCHW tensor (v2:236): instead of transposing 33 MB of activations per batch, the columns of the
     # two 512 x 32768 head weights are permuted to NHWC order once per weight version
@@ -132,12 +161,14 @@ def decoder_infer(dec, z):
     h = ops.linear(h, _d(fc[3].weight), _d(fc[3].bias))
     h, _, _ = ops.layernorm_fwd(h, _d(fc[4].weight), _d(fc[4].bias), eps=fc[4].eps, act=SW, save=False)
     h = ops.nchw_to_nhwc(h.view(B, 512, 8, 8))  # view(-1,512,8,8) (v2:282) -> NHWC
+    bound = pk.ln_bound(fc[4], fc[4].normalized_shape[0])  # |swish(LayerNorm(.))|: range information of the f16x2 convs
     for i in (3, 2, 1):
         rb, up = getattr(dec, "res%d" % i), getattr(dec, "up%d" % i)
-        h = resblock_infer(h, rb, pk)
+        h = resblock_infer(h, rb, pk, bound)
         y = ops.convT2d_fwd(h, pk.conv(up[0]), _d(up[0].bias))
         sc, sh, _, _ = ops.groupnorm_stats(y, _d(up[1].weight), _d(up[1].bias), up[1].num_groups, up[1].eps)
         h = ops.affine_act(y, sc, sh, act=SW, out=y)
+        bound = pk.ln_bound(up[1], (y.shape[3] // up[1].num_groups) * y.shape[1] * y.shape[2])
     f = dec.final_conv
     y = ops.conv2d_fwd(h, pk.conv(f[0]), _d(f[0].bias), 1, 1)
     sc, sh, _, _ = ops.groupnorm_stats(y, _d(f[1].weight), _d(f[1].bias), f[1].num_groups, f[1].eps)
