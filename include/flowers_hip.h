@@ -116,18 +116,20 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
                            int Cout, int kh, int kw, int stride, int pad, int act, float act_param, const float* ln_w,
                            const float* ln_b, float eps, float* scale, float* shift, float* mean, float* rstd, void* ws,
                            size_t ws_bytes, fl_stream_t stream);
-/* 3x3 / stride 1 / pad 1 forward conv in "f16x2" split math (csrc/conv_h2.hip; the ResidualBlock convs of the frozen
- * encoder, v2:159-178). Every fp32 operand is scaled by a power of two and split by round-to-nearest into two fp16
+/* 3x3 / stride 1 / pad 1 and 4x4 / stride 2 / pad 1 forward conv in "f16x2" split math (csrc/conv_h2.hip; the
+ * ResidualBlock and down-sampling convs of the frozen encoder, v2:159-178, v2:191-213). Every fp32 operand is scaled by a power of two and split by round-to-nearest into two fp16
  * pieces x*2^e = h + l (+ <= 2^-22 |x| 2^e); a product is 3 of the 4 piece products on v_mfma_f32_32x32x16_f16 (piece
  * products exact, fp32 accumulation): fp32-equivalent accuracy (measured better than the native fp32 MFMA) at half
  * the matrix instructions of the bf16x3 scheme. fl_pack_weight_f16x2 scales (per tensor, amax -> [2^14,2^15)), splits
- * and lays out the packed weight [Cout][kh*kw*Cin] once (fl_pack_weight_f16x2_bytes(N,K) = 256 + 4*N*K bytes).
+ * and lays out the packed weight [Cout][kh*kw*Cin] once (fl_pack_weight_f16x2_bytes(N,K) = 256 + 4*N*K bytes;
+ * layout 0 for the 3x3 kernel, 1 for the 4x4 one, whose 16-wide k groups pair two taps x 8 channels).
  * Activations are scaled by 2^x_exp, or - when x_amax != NULL - by the power of two that maps *x_amax (a device float
  * >= max|x|, kept by the kernel that produced x) into [2^14,2^15). |x| 2^e >= 65520 yields NaN outputs (loud).
- * Needs H == W in {8,16,32}, Cin % 32 == 0, Cout % 128 == 0, B*H*W % 256 == 0 (fl_conv2d_fwd_f16x2_applicable).
+ * Needs Cout % 128 == 0, B*Ho*Wo % 256 == 0 and: 3x3 H == W in {8,16,32}, Cin % 32 == 0; 4x4 H == W in {16,32,64},
+ * Cin % 8 == 0 (fl_conv2d_fwd_f16x2_applicable).
  * scale != NULL adds the fused LayerNorm2d statistics of fl_conv2d_fwd_instnorm (same outputs and workspace). */
 size_t fl_pack_weight_f16x2_bytes(int N, int K);
-int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, fl_stream_t stream);
+int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, fl_stream_t stream);
 int fl_conv2d_fwd_f16x2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 int fl_conv2d_fwd_f16x2(const float* x, const void* wpack, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                         int kh, int kw, int stride, int pad, int act, float act_param, const float* ln_w, const float* ln_b,

@@ -316,6 +316,264 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 4x4 / stride 2 / pad 1 variant (the three down-sampling convs of the encoder, v2:191-213), same math and pipeline.
+// The input halo of a 256-output tile is (2 rows + 2) x (2 Wo + 2) pixels - 4x the 3x3 case - so a chunk is EIGHT
+// channels and a 16-wide k group pairs two taps: lane half 0 takes tap (ky, 2 kp), half 1 tap (ky, 2 kp + 1), each with
+// the chunk's 8 channels (fl_pack_weight_f16x2 with taps = 16 lays the weights out to match). Even and odd input
+// columns live in separate LDS planes ([pixel][8 halfs], no padding) so that the 32 lanes of a fragment read - 32
+// consecutive output pixels = every second input column - are consecutive 16-byte entries of one plane. 8 k groups
+// (12 MFMAs per wave each) per chunk, 4-slot weight ring.
+template <int WO>
+struct H2Geom4 {
+  static constexpr int BM = 256, BN = 128, W = 2 * WO;
+  static constexpr int R = BM / WO, RI = R < WO ? R : WO, NI = R / RI, HR = 2 * RI + 2, HC = 2 * WO + 2;
+  static constexpr int PXB = 16;
+  // plane row pitch: two input rows (= one output row) further must look like "the next WO entries" to the 64 banks
+  static constexpr int RPB = WO == 32 ? (WO + 1) * PXB : (WO == 16 ? 384 : 192);
+  static constexpr int PAR_B = NI * HR * RPB;      // one column-parity plane
+  static constexpr int PLANE_B = 2 * PAR_B;        // h (or l) plane = even + odd columns
+  static constexpr int ABUF_B = 2 * PLANE_B;
+  static constexpr int NS = 4, SLOT_B = 8192, BOFF = 2 * ABUF_B;
+  static constexpr int LDS_B = BOFF + NS * SLOT_B;
+  static constexpr int P = NI * HR * HC, ITEMS = P * 2, NT = 512, NST = (ITEMS + NT - 1) / NT;
+  static_assert(RPB >= (WO + 1) * PXB && (WO == 32 || (2 * RPB - WO * PXB) % 256 == 0), "row pitch");
+  static_assert(LDS_B <= 160 * 1024, "LDS");
+};
+
+template <int WO, int PRIO>
+__global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
+  using G = H2Geom4<WO>;
+  constexpr int BM = G::BM, BN = G::BN, W = G::W, RI = G::RI, HR = G::HR, HC = G::HC, PXB = G::PXB, RPB = G::RPB;
+  constexpr int PAR_B = G::PAR_B, PLANE_B = G::PLANE_B, ABUF_B = G::ABUF_B, BOFF = G::BOFF, SLOT_B = G::SLOT_B;
+  constexpr int ITEMS = G::ITEMS, NT = G::NT, NST = G::NST;
+  static_assert(NST == 5 || NST == 6, "staging passes");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile_m0 = (tile / g.tiles_n) * BM;
+  const int tile_n0 = (tile % g.tiles_n) * BN;
+  const int img0 = tile_m0 / (WO * WO);
+  const int oy0 = (tile_m0 - img0 * (WO * WO)) / WO;
+  const int Cin = g.Cin, nC = Cin >> 3;  // 8-channel chunks
+
+  const int ea = g.a_amax ? scale_exp_from_amax(*g.a_amax) : g.a_exp;
+  const float sa = __uint_as_float((unsigned)(ea + 127) << 23);
+  const float out_scale = reinterpret_cast<const float*>(g.wpack)[1] * __uint_as_float((unsigned)(127 - ea) << 23);
+
+  // ---- staging descriptors: item i = tid + 512 j -> (halo pixel i >> 1, float4 i & 1)
+  int goff[NST], sdst[NST];
+  unsigned vmask = 0u;
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const int i = tid + NT * j;
+    const int pix = i >> 1, c4 = i & 1;
+    const int nl = pix / (HR * HC), rem = pix - nl * (HR * HC);
+    const int hy = rem / HC, hx = rem - hy * HC;
+    const int iy = 2 * oy0 - 1 + hy, ix = hx - 1;
+    const bool ok = (i < ITEMS) && ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
+    goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
+    sdst[j] = (i < ITEMS) ? (hx & 1) * PAR_B + (nl * HR + hy) * RPB + (hx >> 1) * PXB + c4 * 8 : -1;
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+
+  f32x4v stg[NST];
+  auto stage_load = [&](int c) {
+    const float* xc = g.x + c * 8;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const float* p = xc + goff[j];
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg[j]) : "v"(p) : "memory");
+    }
+  };
+#define FL_STAGE_WAIT4(N)                                                                                                    \
+  do {                                                                                                                       \
+    if constexpr (NST == 5)                                                                                                  \
+      asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4])::"memory"); \
+    else                                                                                                                     \
+      asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                 \
+                   : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[NST - 1])::"memory");      \
+  } while (0)
+  auto stage_store = [&](int buf) {
+    char* dst = smem + buf * ABUF_B;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      if (sdst[j] < 0) continue;
+      const bool ok = (vmask >> j) & 1u;
+      f16x4_t h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float X = ok ? stg[j][e] * sa : 0.f;
+        const _Float16 hh = (_Float16)X;
+        h[e] = hh;
+        l[e] = (_Float16)(X - (float)hh);
+      }
+      *reinterpret_cast<f16x4_t*>(dst + sdst[j]) = h;
+      *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = l;
+    }
+  };
+
+  // A fragment address of k group (ky, kp): this lane's tap is (ky, 2 kp + lh) -> column parity lh, entry ox + kp
+  int abase[2];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int r = wr * 64 + tm * 32 + li;
+    const int nl = r / (RI * WO), rr = r - nl * (RI * WO);
+    const int oyl = rr / WO, ox = rr - oyl * WO;
+    abase[tm] = lh * PAR_B + (nl * HR + 2 * oyl) * RPB + ox * PXB;
+  }
+  const int bfrag = BOFF + wc * 4096 + lane * 16;
+
+  const int nt32 = g.Cout >> 5;
+  const char* wsrc = g.wpack + H2_HDR + ((size_t)(tile_n0 >> 5) * 128 + wid * 64 + lane) * 16;
+  const size_t g16_stride = (size_t)nt32 * 128 * 16;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto dma_grp = [&](int c, int kg, int slot) {  // k group (chunk c, kg = 2 ky + kp): fragments [kg * nC + c]
+    const int cc = c < nC ? c : nC - 1;
+    const char* src = wsrc + (size_t)(kg * nC + cc) * g16_stride;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + BOFF + slot * SLOT_B + wid * 1024), 16, 0, 0);
+  };
+
+  struct Frags {
+    f16x8_t a[2][2];
+    f16x8_t b[2][2];
+  };
+  auto frag_load = [&](Frags& f, int abuf, int grpoff, int slot) {
+    const char* A = smem + abuf * ABUF_B + grpoff;
+    const char* Bp = smem + bfrag + slot * SLOT_B;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) f.b[tn][p] = *reinterpret_cast<const f16x8_t*>(Bp + tn * 2048 + p * 1024);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) f.a[tm][p] = *reinterpret_cast<const f16x8_t*>(A + abase[tm] + p * PLANE_B);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  auto mfma12 = [&](const Frags& f) {
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#define FL_PIECE(pa, pb)                                                                         \
+    _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm][pa], f.b[tn][pb], acc[tm][tn], 0, 0, 0);
+    FL_PIECE(1, 0) FL_PIECE(0, 1) FL_PIECE(0, 0)
+#undef FL_PIECE
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: chunk 0 staged, k groups 0..3 in the ring, fragments of group 0 in registers
+  stage_load(0);
+  dma_grp(0, 0, 0);
+  dma_grp(0, 1, 1);
+  dma_grp(0, 2, 2);
+  dma_grp(0, 3, 3);
+  FL_STAGE_WAIT4(4);
+  stage_store(0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  Frags fA, fB;
+  frag_load(fA, 0, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // one k group: DMA four groups ahead into the slot this group's fragments came from; fragments of the next group under
+  // this group's MFMAs; [counted vmcnt: the DMA of group t+2 has landed] + lgkmcnt(0) + barrier
+  auto grp = [&](auto grp_c, Frags& cur, Frags& nxt, int c) {
+    constexpr int T = decltype(grp_c)::value;
+    constexpr int T4 = (T + 4) % 8, C4 = (T + 4) / 8;
+    constexpr int T1 = (T + 1) % 8, C1 = (T + 1) / 8;
+    dma_grp(c + C4, T4, T % 4);
+    if constexpr (T == 0) stage_load(c + 1 < nC ? c + 1 : c);
+    frag_load(nxt, (c + C1) & 1, (T1 >> 1) * RPB + (T1 & 1) * PXB, T1 % 4);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma12(cur);
+    __builtin_amdgcn_sched_barrier(0);
+    // outstanding, oldest first, at the end of group t: DMA(t+2) [issued at t-2], DMA(t+3), DMA(t+4) - and the NST halo
+    // loads issued at t = 0 right after DMA(4)
+    if constexpr (T == 0 || T == 1 || T == 2) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST + 2) : "memory");
+    } else if constexpr (T == 3) {
+      FL_STAGE_WAIT4(2);  // the halo loads are older than DMA(t+2) now: complete
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    if constexpr (T == 4) stage_store((c + 1) & 1);  // the other buffer: last read while group 6 of the previous chunk ran
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto chunk = [&](int c) {  // 8 groups: the register sets alternate and come back to fA
+    grp(std::integral_constant<int, 0>{}, fA, fB, c);
+    grp(std::integral_constant<int, 1>{}, fB, fA, c);
+    grp(std::integral_constant<int, 2>{}, fA, fB, c);
+    grp(std::integral_constant<int, 3>{}, fB, fA, c);
+    grp(std::integral_constant<int, 4>{}, fA, fB, c);
+    grp(std::integral_constant<int, 5>{}, fB, fA, c);
+    grp(std::integral_constant<int, 6>{}, fA, fB, c);
+    grp(std::integral_constant<int, 7>{}, fB, fA, c);
+  };
+#pragma unroll 1
+  for (int c = 0; c < nC; ++c) chunk(c);
+#undef FL_STAGE_WAIT4
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float st1[2], st2[2], bv[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    st1[tn] = st2[tn] = 0.f;
+    bv[tn] = g.bias ? g.bias[tile_n0 + wc * 64 + tn * 32 + li] : 0.f;
+  }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = tile_m0 + wr * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      float* yrow = g.y + (size_t)m * g.Cout + tile_n0 + wc * 64 + li;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const float v = fl::apply_act(acc[tm][tn][e] * out_scale + bv[tn], g.act, g.act_param);
+        yrow[tn * 32] = v;
+        st1[tn] += v;
+        st2[tn] += v * v;
+      }
+    }
+  }
+  if (g.stats) {
+    const int grp_i = (tile_m0 + wr * 64) / 64;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const float a = st1[tn] + __shfl_xor(st1[tn], 32, 64);
+      const float b = st2[tn] + __shfl_xor(st2[tn], 32, 64);
+      const int col = tile_n0 + wc * 64 + tn * 32 + li;
+      if (lh == 0) {
+        g.stats[((size_t)grp_i * 2) * g.Cout + col] = a;
+        g.stats[((size_t)grp_i * 2 + 1) * g.Cout + col] = b;
+      }
+    }
+  }
+}
+
 // ---- weight pack: fp32 [N][K] -> header + [16-k group][32-col tile][piece h|l][lane][8 halfs]
 __global__ void h2_amax_kernel(const float* __restrict__ w, long long n, unsigned* hdr) {
   float m = 0.f;
@@ -325,7 +583,10 @@ __global__ void h2_amax_kernel(const float* __restrict__ w, long long n, unsigne
   if ((threadIdx.x & 63) == 0) atomicMax(hdr, __float_as_uint(m));  // non-negative floats order like their bits
 }
 
-__global__ void h2_pack_kernel(const float* __restrict__ w, char* __restrict__ out, int N, int K) {
+// layout 0: k group g16 = 16 consecutive k (3x3 conv: [tap][Cin/16] groups; any K-contiguous operand);
+// layout 1 (4x4 taps, K = 16 Cin): group g16 = kg * (Cin/8) + c8 with kg = 2 ky + kp; its k slot 8 lh + j is tap
+// (ky, 2 kp + lh), channel 8 c8 + j - the pairing conv4x4s2_h2_kernel reads
+__global__ void h2_pack_kernel(const float* __restrict__ w, char* __restrict__ out, int N, int K, int layout) {
   const unsigned* hdr = reinterpret_cast<const unsigned*>(out);
   const int e = scale_exp_from_amax(hdr[0]);
   const float s = __uint_as_float((unsigned)(e + 127) << 23);
@@ -337,7 +598,13 @@ __global__ void h2_pack_kernel(const float* __restrict__ w, char* __restrict__ o
   const long long gt = i >> 6;
   const int t = (int)(gt % nt);
   const long long g16 = gt / nt;
-  const float* row = w + (long long)(32 * t + lr) * K + 16 * g16 + 8 * lh;  // k slots of this lane: 8*lh + j
+  long long k0 = 16 * g16 + 8 * lh;  // k slots of this lane: 8*lh + j
+  if (layout == 1) {
+    const int Cin = K >> 4, nC8 = Cin >> 3;
+    const int kg = (int)(g16 / nC8), c8 = (int)(g16 - (long long)kg * nC8);
+    k0 = (long long)((kg >> 1) * 4 + 2 * (kg & 1) + lh) * Cin + 8 * c8;
+  }
+  const float* row = w + (long long)(32 * t + lr) * K + k0;
   const float4 q0 = *reinterpret_cast<const float4*>(row), q1 = *reinterpret_cast<const float4*>(row + 4);
   const float x[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
   f16x8_t h, l;
@@ -357,6 +624,8 @@ template <int W>
 void h2_set_attr() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, H2Geom<W>::LDS_B);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, H2Geom<W>::LDS_B);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, H2Geom4<W>::LDS_B);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, H2Geom4<W>::LDS_B);
 }
 
 }  // namespace
@@ -370,13 +639,20 @@ bool conv3x3_h2_applicable(const float* x, int B, int H, int W, int Cin, int Cou
   return false;
 }
 
-int launch_conv3x3_h2(const float* x, const void* wpack, const float* bias, float* y, float* stats, const unsigned* a_amax,
-                      int a_exp, int B, int H, int W, int Cin, int Cout, int act, float act_param, hipStream_t s) {
+bool conv4x4s2_h2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
+  if (Cin % 8 || Cout % 128 || (reinterpret_cast<uintptr_t>(x) & 15) || H != W) return false;
+  if ((long long)B * H * W * Cin >= (1ll << 31)) return false;
+  if (kh == 4 && kw == 4 && stride == 2 && pad == 1 && (W == 16 || W == 32 || W == 64)) return ((long long)B * (H / 2) * (W / 2)) % 256 == 0;
+  return false;
+}
+
+int launch_conv_h2(const float* x, const void* wpack, const float* bias, float* y, float* stats, const unsigned* a_amax,
+                   int a_exp, int B, int H, int W, int Cin, int Cout, int ksize, int act, float act_param, hipStream_t s) {
   H2Args g;
   g.x = x; g.wpack = reinterpret_cast<const char*>(wpack); g.bias = bias; g.y = y; g.stats = stats;
   g.a_amax = a_amax; g.a_exp = a_exp;
   g.Cin = Cin; g.Cout = Cout; g.tiles_n = Cout / 128; g.act = act; g.act_param = act_param;
-  g.M = B * H * W;
+  g.M = ksize == 3 ? B * H * W : B * (H / 2) * (W / 2);
   const int blocks = (g.M / 256) * g.tiles_n;
   static std::once_flag once;
   std::call_once(once, [] { h2_set_attr<32>(); h2_set_attr<16>(); h2_set_attr<8>(); });
@@ -387,23 +663,35 @@ int launch_conv3x3_h2(const float* x, const void* wpack, const float* bias, floa
     if (prio) hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 1>), dim3(blocks), dim3(512), H2Geom<WW>::LDS_B, s, g);    \
     else hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 0>), dim3(blocks), dim3(512), H2Geom<WW>::LDS_B, s, g);         \
   } while (0)
-  if (W == 32) FL_LAUNCH(32);
-  else if (W == 16) FL_LAUNCH(16);
-  else FL_LAUNCH(8);
+#define FL_LAUNCH4(WW)                                                                                               \
+  do {                                                                                                             \
+    if (prio) hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 1>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B, s, g);  \
+    else hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 0>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B, s, g);       \
+  } while (0)
+  if (ksize == 3) {
+    if (W == 32) FL_LAUNCH(32);
+    else if (W == 16) FL_LAUNCH(16);
+    else FL_LAUNCH(8);
+  } else {
+    if (W == 64) FL_LAUNCH4(32);
+    else if (W == 32) FL_LAUNCH4(16);
+    else FL_LAUNCH4(8);
+  }
 #undef FL_LAUNCH
-  return fl::check_launch("conv3x3_h2_kernel");
+#undef FL_LAUNCH4
+  return fl::check_launch("conv_h2_kernel");
 }
 
 size_t pack_weight_f16x2_bytes(int N, int K) { return (size_t)H2_HDR + (size_t)N * K * 4; }
 
-int pack_weight_f16x2(const float* w, void* out, int N, int K, hipStream_t s) {
+int pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, hipStream_t s) {
   if (hipMemsetAsync(out, 0, H2_HDR, s) != hipSuccess) return fl::check_launch("pack_weight_f16x2 memset");
   const long long n = (long long)N * K;
   int blocks = fl::cdiv(n, 256 * 8);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(h2_amax_kernel, dim3(blocks), dim3(256), 0, s, w, n, reinterpret_cast<unsigned*>(out));
   const long long total = (long long)(K / 16) * (N / 32) * 64;
-  hipLaunchKernelGGL(h2_pack_kernel, dim3(fl::cdiv(total, 256)), dim3(256), 0, s, w, reinterpret_cast<char*>(out), N, K);
+  hipLaunchKernelGGL(h2_pack_kernel, dim3(fl::cdiv(total, 256)), dim3(256), 0, s, w, reinterpret_cast<char*>(out), N, K, layout);
   return fl::check_launch("h2_pack_kernel");
 }
 
@@ -415,14 +703,16 @@ extern "C" {
 size_t fl_pack_weight_f16x2_bytes(int N, int K) { return fl::pack_weight_f16x2_bytes(N, K); }
 
 // w: [N][K] fp32 (a packed conv weight [Cout][kh][kw][Cin]), N % 32 == 0, K % 16 == 0
-int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, fl_stream_t stream) {
+int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, fl_stream_t stream) {
   FL_REQUIRE(w && out && N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, "fl_pack_weight_f16x2: N=%d (mult. of 32), K=%d (mult. of 16)", N, K);
+  FL_REQUIRE(layout == 0 || (layout == 1 && K % 128 == 0), "fl_pack_weight_f16x2: layout %d (0 = 16-k groups, 1 = 4x4 tap pairs, K = 16 Cin, Cin %% 8 == 0)", layout);
   FL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0, "fl_pack_weight_f16x2: 16-byte alignment");
-  return fl::pack_weight_f16x2(w, out, N, K, reinterpret_cast<hipStream_t>(stream));
+  return fl::pack_weight_f16x2(w, out, N, K, layout, reinterpret_cast<hipStream_t>(stream));
 }
 
 int fl_conv2d_fwd_f16x2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
-  return fl::conv3x3_h2_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad) ? 1 : 0;
+  return (fl::conv3x3_h2_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad) ||
+          fl::conv4x4s2_h2_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad)) ? 1 : 0;
 }
 
 int fl_conv2d_fwd_f16x2(const float* x, const void* wpack, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
@@ -430,19 +720,20 @@ int fl_conv2d_fwd_f16x2(const float* x, const void* wpack, const float* bias, fl
                         float eps, float* scale, float* shift, float* mean, float* rstd, const float* x_amax, int x_exp,
                         void* ws, size_t ws_bytes, fl_stream_t stream) {
   FL_REQUIRE(x && wpack && y, "fl_conv2d_fwd_f16x2: null operand");
-  FL_REQUIRE(fl::conv3x3_h2_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad),
+  FL_REQUIRE(fl_conv2d_fwd_f16x2_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad),
              "fl_conv2d_fwd_f16x2: unsupported shape (B=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d)", B, H, W, Cin, Cout, kh, kw, stride, pad);
   FL_REQUIRE(x_exp >= -100 && x_exp <= 100, "fl_conv2d_fwd_f16x2: x_exp %d out of range", x_exp);
-  const int HW = H * W;
+  const int Ho = kh == 3 ? H : H / 2, Wo = kh == 3 ? W : W / 2;
+  const int HW = Ho * Wo;
   const bool stats = scale != nullptr;
   if (stats) {
-    FL_REQUIRE(shift && act == FL_ACT_NONE && HW % 64 == 0, "fl_conv2d_fwd_f16x2: fused statistics need shift, act NONE, H*W %% 64 == 0");
-    FL_REQUIRE(ws && ws_bytes >= fl_conv2d_fwd_instnorm_workspace_bytes(B, H, W, Cout), "fl_conv2d_fwd_f16x2: workspace too small");
+    FL_REQUIRE(shift && act == FL_ACT_NONE && HW % 64 == 0, "fl_conv2d_fwd_f16x2: fused statistics need shift, act NONE, Ho*Wo %% 64 == 0");
+    FL_REQUIRE(ws && ws_bytes >= fl_conv2d_fwd_instnorm_workspace_bytes(B, Ho, Wo, Cout), "fl_conv2d_fwd_f16x2: workspace too small");
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float* part = stats ? reinterpret_cast<float*>(ws) : nullptr;
-  const int rc = fl::launch_conv3x3_h2(x, wpack, bias, y, part, reinterpret_cast<const unsigned*>(x_amax), x_exp, B, H, W, Cin, Cout,
-                                       act, act_param, s);
+  const int rc = fl::launch_conv_h2(x, wpack, bias, y, part, reinterpret_cast<const unsigned*>(x_amax), x_exp, B, H, W, Cin, Cout, kh,
+                                    act, act_param, s);
   if (rc || !stats) return rc;
   return fl::launch_conv_inorm_finalize(part, ln_w, ln_b, eps, scale, shift, mean, rstd, B, HW, Cout, HW / 64, s);
 }

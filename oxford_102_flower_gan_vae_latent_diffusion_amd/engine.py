@@ -133,11 +133,16 @@ def encoder_infer(enc, x):
     y, (sc, sh, _, _) = ops.conv2d_fwd_instnorm(h, pk.conv(c0), _d(c0.bias), 1, 1, _d(ln0.weight), _d(ln0.bias), ln0.eps)
     h = ops.affine_act(y, sc, sh, act=SW, out=y)
     feats = [h]
+    # range information of the f16x2 convs: |swish(ln(.))| <= the LayerNorm2d bound; a ResidualBlock adds its input's bound
+    bound = pk.ln_bound(ln0, y.shape[1] * y.shape[2])
     for i in (1, 2, 3):
         dn, rb = getattr(enc, "down%d" % i), getattr(enc, "res%d" % i)
-        y, sc, sh = conv_ln_infer(h, dn[0], dn[1], 2, 1, pk)
+        y, sc, sh = conv_ln_infer(h, dn[0], dn[1], 2, 1, pk, bound)
+        HW = y.shape[1] * y.shape[2]
         h = ops.affine_act(y, sc, sh, act=SW, out=y)
-        h = resblock_infer(h, rb, pk, pk.ln_bound(dn[1], y.shape[1] * y.shape[2]))  # |swish(ln(.))| <= the ln bound
+        bd = pk.ln_bound(dn[1], HW)
+        h = resblock_infer(h, rb, pk, bd)
+        bound = pk.ln_bound(rb.ln2, HW, bd)
         feats.append(h)
     # x.view(B,-1) of the NCHW tensor (v2:236): instead of transposing 33 MB of activations per batch, the columns of the
     # two 512 x 32768 head weights are permuted to NHWC order once per weight version

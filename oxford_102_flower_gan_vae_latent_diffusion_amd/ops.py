@@ -262,12 +262,14 @@ def conv2d_fwd_presplit(x, wsplit, geom, bias, stride, pad, act=ACT_NONE, act_pa
 
 
 def pack_weight_f16x2(wp):
-    """packed conv weight [O][kh][kw][I] -> header + fp16 (h | l) pieces in MFMA-fragment order for conv2d_fwd_f16x2."""
+    """packed conv weight [O][kh][kw][I] (3x3 or 4x4) -> header + fp16 (h | l) pieces in MFMA-fragment order for
+    conv2d_fwd_f16x2 (the 4x4 kernel's k groups pair two taps x 8 channels: layout 1)."""
     _chk(wp)
     N = wp.shape[0]
     K = wp.numel() // N
+    layout = 1 if (wp.dim() == 4 and wp.shape[1] == 4 and wp.shape[2] == 4) else 0
     out = torch.empty(_lib.load().fl_pack_weight_f16x2_bytes(N, K), dtype=torch.uint8, device=wp.device)
-    _lib.call("fl_pack_weight_f16x2", _p(wp), _p(out), N, K, _stream())
+    _lib.call("fl_pack_weight_f16x2", _p(wp), _p(out), N, K, layout, _stream())
     return out
 
 
@@ -278,19 +280,20 @@ def f16x2_ok(x, Cout, kh, kw, stride, pad):
 
 def conv2d_fwd_f16x2(x, wpack, geom, bias, stride=1, pad=1, act=ACT_NONE, act_param=0.0, ln_w=None, ln_b=None, eps=1e-5,
                      out=None, x_amax=None, x_exp=6):
-    """3x3 s1 p1 conv forward in f16x2 split math (geom = (Cout, kh, kw, Cin) of the packed weight). x_amax: device float
+    """3x3 s1 p1 / 4x4 s2 p1 conv forward in f16x2 split math (geom = (Cout, kh, kw, Cin) of the packed weight). x_amax: device float
     bounding max|x| (else activations are scaled by 2^x_exp). With ln_w/ln_b: also the fused LayerNorm2d statistics."""
     _chk(x, bias, ln_w, ln_b, out, x_amax)
     B, H, W, Cin = x.shape
     Cout, kh, kw, Ci2 = geom
     assert Ci2 == Cin
-    y = out if out is not None else new((B, H, W, Cout), x)
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    y = out if out is not None else new((B, Ho, Wo, Cout), x)
     if ln_w is None:
         _lib.call("fl_conv2d_fwd_f16x2", _p(x), _p(wpack), _p(bias), _p(y), B, H, W, Cin, Cout, kh, kw, stride, pad, act,
                   float(act_param), None, None, float(eps), None, None, None, None, _p(x_amax), int(x_exp), None, 0, _stream())
         return y
     scale, shift, mean, rstd = (new((B, Cout), x) for _ in range(4))
-    wsp, wsn = _ws(_lib.load().fl_conv2d_fwd_instnorm_workspace_bytes(B, H, W, Cout), x)
+    wsp, wsn = _ws(_lib.load().fl_conv2d_fwd_instnorm_workspace_bytes(B, Ho, Wo, Cout), x)
     _lib.call("fl_conv2d_fwd_f16x2", _p(x), _p(wpack), _p(bias), _p(y), B, H, W, Cin, Cout, kh, kw, stride, pad, act,
               float(act_param), _p(ln_w), _p(ln_b), float(eps), _p(scale), _p(shift), _p(mean), _p(rstd), _p(x_amax), int(x_exp),
               wsp, wsn, _stream())

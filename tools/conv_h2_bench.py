@@ -1,5 +1,5 @@
-"""f16x2 3x3 conv kernel (csrc/conv_h2.hip) vs the r01 bf16x3 halo kernel and an fp64 reference, on the six
-ResidualBlock conv shapes of the frozen encoder at B=256. Usage: python tools/conv_h2_bench.py [reps]"""
+"""f16x2 conv kernels (csrc/conv_h2.hip) vs the r01 bf16x3 halo kernels and an fp64 reference, on the nine conv shapes
+of the frozen encoder at B=256. Usage: python tools/conv_h2_bench.py [reps]"""
 import os
 import sys
 
@@ -9,16 +9,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oxford_102_flower_gan_vae_latent_diffusion_amd import ops  # noqa: E402
 
 
-def ref_points(x, w, bias, pts):
-    """fp64 conv at a few output points: x (B,H,W,C) cpu, w (O,3,3,C) cpu."""
+def ref_points(x, w, bias, pts, k, s, p):
+    """fp64 conv at a few output points: x (B,H,W,C) cpu, w (O,k,k,C) cpu."""
     B, H, W, C = x.shape
     xd, wd = x.double(), w.double()
     out = []
     for (b, oy, ox) in pts:
         acc = bias.double().clone()
-        for dy in range(3):
-            for dx in range(3):
-                iy, ix = oy + dy - 1, ox + dx - 1
+        for dy in range(k):
+            for dx in range(k):
+                iy, ix = oy * s + dy - p, ox * s + dx - p
                 if 0 <= iy < H and 0 <= ix < W:
                     acc += wd[:, dy, dx, :] @ xd[b, iy, ix, :]
         out.append(acc)
@@ -30,23 +30,29 @@ def main():
     B = int(os.environ.get("B", "256"))
     dev = torch.device("cuda:0")
     ok_all = True
-    for (H, C) in ((32, 128), (16, 256), (8, 512)):
-        g = torch.Generator().manual_seed(H)
-        x = torch.randn(B, H, H, C, generator=g)
+    tot = {"bf16x3 halo": 0.0, "f16x2": 0.0}
+    shapes = []
+    for (C, H) in ((128, 32), (256, 16), (512, 8)):
+        shapes.append((2 * H, C // 2, C, 4, 2, 1, 1))
+        shapes.append((H, C, C, 3, 1, 1, 2))
+    for (H, Ci, Co, k, s, p, mult) in shapes:
+        g = torch.Generator().manual_seed(H + k)
+        x = torch.randn(B, H, H, Ci, generator=g)
         x = x * torch.sigmoid(x)  # swish-shaped activations
-        w = torch.randn(C, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5
-        bias = torch.randn(C, generator=g) * 0.1
+        w = torch.randn(Co, k, k, Ci, generator=g) * (2.0 / (k * k * Ci)) ** 0.5
+        bias = torch.randn(Co, generator=g) * 0.1
         xd, wd, bd = x.to(dev), w.to(dev), bias.to(dev)
-        pts = [(0, 0, 0), (B - 1, H - 1, H - 1), (3, 0, H - 1), (5, H - 1, 0), (7, H // 2, H // 2), (B // 2, 1, 2),
-               (B - 2, H - 2, 1), (11, 3, H - 2)]
-        ref = ref_points(x, w, bias, pts)
+        Ho = (H + 2 * p - k) // s + 1
+        pts = [(0, 0, 0), (B - 1, Ho - 1, Ho - 1), (3, 0, Ho - 1), (5, Ho - 1, 0), (7, Ho // 2, Ho // 2), (B // 2, 1, 2),
+               (B - 2, Ho - 2, 1), (11, 3, Ho - 2)]
+        ref = ref_points(x, w, bias, pts, k, s, p)
         wsp = ops.split_pack_weight(wd)
         wh2 = ops.pack_weight_f16x2(wd)
         geom = tuple(w.shape)
-        y0 = ops.conv2d_fwd_presplit(xd, wsp, geom, bd, 1, 1)
-        y1 = ops.conv2d_fwd_f16x2(xd, wh2, geom, bd)
+        y0 = ops.conv2d_fwd_presplit(xd, wsp, geom, bd, s, p)
+        y1 = ops.conv2d_fwd_f16x2(xd, wh2, geom, bd, s, p)
         amax = xd.abs().max().reshape(1)  # harness only
-        y2 = ops.conv2d_fwd_f16x2(xd, wh2, geom, bd, x_amax=amax)
+        y2 = ops.conv2d_fwd_f16x2(xd, wh2, geom, bd, s, p, x_amax=amax)
         torch.cuda.synchronize()
         d01 = (y0 - y1).abs().max().item()
         d12 = (y1 - y2).abs().max().item()
@@ -57,26 +63,22 @@ def main():
             return (got - ref).abs().max().item() / ref.abs().max().item()
 
         e0, e1, e2 = err(y0), err(y1), err(y2)
-        # fused statistics
-        lnw, lnb = torch.ones(C, device=dev), torch.zeros(C, device=dev)
-        _, (sc0, sh0, _, _) = ops.conv2d_fwd_presplit(xd, wsp, geom, bd, 1, 1, ln_w=lnw, ln_b=lnb)
-        _, (sc1, sh1, _, _) = ops.conv2d_fwd_f16x2(xd, wh2, geom, bd, ln_w=lnw, ln_b=lnb)
+        lnw, lnb = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
+        _, (sc0, sh0, _, _) = ops.conv2d_fwd_presplit(xd, wsp, geom, bd, s, p, ln_w=lnw, ln_b=lnb)
+        _, (sc1, sh1, _, _) = ops.conv2d_fwd_f16x2(xd, wh2, geom, bd, s, p, ln_w=lnw, ln_b=lnb, x_amax=amax)
         ds = max((sc0 - sc1).abs().max().item() / sc0.abs().max().item(), (sh0 - sh1).abs().max().item() / max(sh0.abs().max().item(), 1e-9))
-        # tiny activations with the static exponent: both pieces of small values in fp16's subnormal range
-        xs = xd * 1e-3
-        ys0 = ops.conv2d_fwd_presplit(xs, wsp, geom, None, 1, 1)
-        ys1 = ops.conv2d_fwd_f16x2(xs, wh2, geom, None)
-        ys2 = ops.conv2d_fwd_f16x2(xs, wh2, geom, None, x_amax=amax * 1e-3)
+        xs = xd * 1e-3  # tiny activations with the static exponent: low pieces in fp16's subnormal range
+        ys0 = ops.conv2d_fwd_presplit(xs, wsp, geom, None, s, p)
+        ys1 = ops.conv2d_fwd_f16x2(xs, wh2, geom, None, s, p)
         dsub = (ys0 - ys1).abs().max().item() / ys0.abs().max().item()
-        dsub2 = (ys0 - ys2).abs().max().item() / ys0.abs().max().item()
         nan = bool(torch.isnan(y1).any().item())
-        good = d01 / sc < 2e-6 and e1 < 2e-6 and e2 < 2e-6 and ds < 1e-5 and not nan
+        good = d01 / sc < 6e-6 and e1 < 1.5 * e0 + 1e-7 and e2 < 1.5 * e0 + 1e-7 and ds < 1e-5 and dsub < 1e-5 and not nan
         ok_all &= good
-        print("H=%2d C=%3d  |bf16x3-f16x2|/max %.2e  |static-amax| %.2e  err vs fp64: bf16x3 %.2e f16x2 %.2e (amax %.2e)  stats %.2e"
-              "  tiny-x: static %.2e amax %.2e  %s" % (H, C, d01 / sc, d12 / sc, e0, e1, e2, ds, dsub, dsub2, "OK" if good else "FAIL"), flush=True)
-        fl = 2.0 * B * H * H * C * 9 * C
-        for name, run in (("bf16x3 halo", lambda: ops.conv2d_fwd_presplit(xd, wsp, geom, bd, 1, 1, out=y0)),
-                          ("f16x2", lambda: ops.conv2d_fwd_f16x2(xd, wh2, geom, bd, out=y1))):
+        print("%dx%d s%d H=%2d Ci=%3d Co=%3d  |bf16x3-f16x2|/max %.2e  |static-amax| %.2e  err vs fp64: bf16x3 %.2e f16x2 %.2e (amax %.2e)"
+              "  stats %.2e  tiny-x %.2e  %s" % (k, k, s, H, Ci, Co, d01 / sc, d12 / sc, e0, e1, e2, ds, dsub, "OK" if good else "FAIL"), flush=True)
+        fl = 2.0 * B * Ho * Ho * Co * k * k * Ci
+        for name, run in (("bf16x3 halo", lambda: ops.conv2d_fwd_presplit(xd, wsp, geom, bd, s, p, out=y0)),
+                          ("f16x2", lambda: ops.conv2d_fwd_f16x2(xd, wh2, geom, bd, s, p, out=y1, x_amax=amax))):
             for _ in range(5):
                 run()
             e_0, e_1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -86,7 +88,9 @@ def main():
             e_1.record()
             e_1.synchronize()
             ms = e_0.elapsed_time(e_1) / reps
+            tot[name] += ms * mult
             print("    %-12s %8.4f ms  %7.1f TFLOP/s fp32-equivalent" % (name, ms, fl / ms / 1e9), flush=True)
+    print("nine encoder convs: bf16x3 halo %.3f ms, f16x2 %.3f ms" % (tot["bf16x3 halo"], tot["f16x2"]))
     print("ALL OK" if ok_all else "SOME FAILED")
     return 0 if ok_all else 1
 
