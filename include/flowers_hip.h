@@ -127,14 +127,17 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
  * >= max|x|, kept by the kernel that produced x) into [2^14,2^15). |x| 2^e >= 65520 yields NaN outputs (loud).
  * Needs Cout % 128 == 0, B*Ho*Wo % 256 == 0 and: 3x3 H == W in {8,16,32}, Cin % 32 == 0; 4x4 H == W in {16,32,64},
  * Cin % 8 == 0 (fl_conv2d_fwd_f16x2_applicable).
- * scale != NULL adds the fused LayerNorm2d statistics of fl_conv2d_fwd_instnorm (same outputs and workspace). */
+ * scale != NULL adds the fused LayerNorm2d statistics of fl_conv2d_fwd_instnorm (same outputs and workspace).
+ * pre_scale / pre_shift ([B][Cin], both or neither): the conv consumes swish(x * pre_scale[b,c] + pre_shift[b,c]) - the
+ * producer's LayerNorm2d-apply + Swish (v2:163-164, v2:193-194) fused into the halo staging, so that pass never
+ * touches HBM; x_amax / x_exp then bound the transformed values. */
 size_t fl_pack_weight_f16x2_bytes(int N, int K);
 int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, fl_stream_t stream);
 int fl_conv2d_fwd_f16x2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 int fl_conv2d_fwd_f16x2(const float* x, const void* wpack, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                         int kh, int kw, int stride, int pad, int act, float act_param, const float* ln_w, const float* ln_b,
                         float eps, float* scale, float* shift, float* mean, float* rstd, const float* x_amax, int x_exp,
-                        void* ws, size_t ws_bytes, fl_stream_t stream);
+                        const float* pre_scale, const float* pre_shift, void* ws, size_t ws_bytes, fl_stream_t stream);
 /* dx = conv_transpose(dy, w): input gradient of the conv above (stride 1 any
  * kernel; stride 2 only for 4x4 p1).  dy:(B,Ho,Wo,Cout) -> dx:(B,H,W,Cin).
  * wp is the SAME packed weight as the forward. */
@@ -227,6 +230,11 @@ int fl_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
  * ------------------------------------------------------------------------ */
 int fl_res_tail_map(const float* y, const float* scale, const float* shift, const float* s, int s_per_image, float* map,
                     int B, int HW, int C, fl_stream_t stream);
+/* fl_res_tail_out_pre: as fl_res_tail_out, with the residual given before its LayerNorm2d-apply + Swish:
+ * xres := swish(xres * xres_scale[b,c] + xres_shift[b,c]) (the block input is never materialised, engine.encoder_infer). */
+int fl_res_tail_out_pre(const float* y, const float* scale, const float* shift, const float* s, int s_per_image, const float* map,
+                        const float* saw, const float* xres, const float* xres_scale, const float* xres_shift, float* out,
+                        float* att_out, int B, int H, int W, int C, int final_swish, fl_stream_t stream);
 int fl_res_tail_out(const float* y, const float* scale, const float* shift, const float* s, int s_per_image,
                     const float* map,
                     const float* saw, const float* xres, float* out, float* att_out, int B, int H, int W, int C,

@@ -77,7 +77,8 @@ template <int LPP>
 __global__ void res_tail_out_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                     const float* __restrict__ shift, const float* __restrict__ s,
                                     const float* __restrict__ map, const float* __restrict__ saw,
-                                    const float* __restrict__ xres, float* __restrict__ out, float* __restrict__ att_out,
+                                    const float* __restrict__ xres, const float* __restrict__ xs,
+                                    const float* __restrict__ xh, float* __restrict__ out, float* __restrict__ att_out,
                                     int B, int H, int W, int C, int final_swish, int s_per_image) {
   constexpr int PPW = 64 / LPP;
   __shared__ float wsm[98];
@@ -119,7 +120,12 @@ __global__ void res_tail_out_kernel(const float* __restrict__ y, const float* __
       float4 u = tail_u(y, scale, shift, s, off, (long long)b * C + c4 * 4, (s_per_image ? (long long)b * C : 0) + c4 * 4);
       u.x *= att; u.y *= att; u.z *= att; u.w *= att;
       if (xres) {
-        const float4 r = ld4(xres + off);
+        float4 r = ld4(xres + off);
+        if (xs) {  // the residual before its LayerNorm2d-apply + Swish (same expression as affine_act_kernel)
+          const float4 a = ld4(xs + (long long)b * C + c4 * 4), d = ld4(xh + (long long)b * C + c4 * 4);
+          r.x = fl::swish_acc(r.x * a.x + d.x); r.y = fl::swish_acc(r.y * a.y + d.y);
+          r.z = fl::swish_acc(r.z * a.z + d.z); r.w = fl::swish_acc(r.w * a.w + d.w);
+        }
         u.x += r.x; u.y += r.y; u.z += r.z; u.w += r.w;
       }
       if (final_swish) {
@@ -164,16 +170,17 @@ int fl_res_tail_map(const float* y, const float* scale, const float* shift, cons
 
 // out = [swish]( u * sigmoid(conv7x7(map, saw)) + xres ), u as above. map NULL -> att = 1.
 // att_out (B,H*W) optional (saved for backward). Replaces v2:79-81 and v2:176-177.
-int fl_res_tail_out(const float* y, const float* scale, const float* shift, const float* s, int s_per_image, const float* map,
-                    const float* saw, const float* xres, float* out, float* att_out, int B, int H, int W, int C,
-                    int final_swish, fl_stream_t stream) {
+int fl_res_tail_out_pre(const float* y, const float* scale, const float* shift, const float* s, int s_per_image, const float* map,
+                        const float* saw, const float* xres, const float* xres_scale, const float* xres_shift, float* out,
+                        float* att_out, int B, int H, int W, int C, int final_swish, fl_stream_t stream) {
   FL_REQUIRE(y && out && C % 4 == 0, "fl_res_tail_out: bad args");
+  FL_REQUIRE((xres_scale == nullptr) == (xres_shift == nullptr) && (!xres_scale || xres), "fl_res_tail_out_pre: xres_scale / xres_shift / xres");
   FL_REQUIRE((map == nullptr) || (saw != nullptr), "fl_res_tail_out: map needs conv weights");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long long npix = (long long)B * H * W;
   if (npix == 0) return FL_OK;
   const int C4 = C / 4;
-#define LAUNCH_OUT(L) hipLaunchKernelGGL(res_tail_out_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, saw, xres, out, att_out, B, H, W, C, final_swish, s_per_image)
+#define LAUNCH_OUT(L) hipLaunchKernelGGL(res_tail_out_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, saw, xres, xres_scale, xres_shift, out, att_out, B, H, W, C, final_swish, s_per_image)
   if (C4 >= 64) LAUNCH_OUT(64);
   else if (C4 >= 32) LAUNCH_OUT(32);
   else if (C4 >= 16) LAUNCH_OUT(16);
@@ -181,6 +188,13 @@ int fl_res_tail_out(const float* y, const float* scale, const float* shift, cons
   else LAUNCH_OUT(1);
 #undef LAUNCH_OUT
   return fl::check_launch("res_tail_out_kernel");
+}
+
+int fl_res_tail_out(const float* y, const float* scale, const float* shift, const float* s, int s_per_image, const float* map,
+                    const float* saw, const float* xres, float* out, float* att_out, int B, int H, int W, int C,
+                    int final_swish, fl_stream_t stream) {
+  return fl_res_tail_out_pre(y, scale, shift, s, s_per_image, map, saw, xres, nullptr, nullptr, out, att_out, B, H, W, C, final_swish,
+                             stream);
 }
 
 }  // extern "C"

@@ -45,9 +45,16 @@ struct H2Args {
   float* stats;
   const unsigned* a_amax;  // optional device word: bits of a bound on max|x|; NULL -> a_exp
   int a_exp;
-  int Cin, Cout, M, tiles_n, act;
+  // optional pre-op fused into the halo staging (template PRE): the conv consumes swish(x * pre_scale[b,c] + pre_shift[b,c]),
+  // i.e. the producer's LayerNorm2d-apply + Swish pass (fl_affine_act) never touches HBM
+  const float* pre_scale;
+  const float* pre_shift;
+  int Cin, Cout, M, tiles_n, ntiles, act;
   float act_param;
 };
+
+// x * sigmoid(x) on the fast transcendental pipe (v_exp_f32 + v_rcp_f32: a few ulp, far inside the parity tolerance)
+__device__ __forceinline__ float swish_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 __device__ __forceinline__ int scale_exp_from_amax(unsigned bits) {
   const int E = (int)((bits >> 23) & 0xffu);
@@ -72,10 +79,10 @@ struct H2Geom {
   static_assert(LDS_B <= 160 * 1024, "LDS");
 };
 
-template <int W, int PRIO>
+template <int W, int PRE>
 __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
   using G = H2Geom<W>;
-  constexpr int BM = G::BM, BN = G::BN, RI = G::RI, HR = G::HR, HC = G::HC, PXB = G::PXB, RPB = G::RPB;
+  constexpr int BM = G::BM, BN = G::BN, RI = G::RI, NI = G::NI, HR = G::HR, HC = G::HC, PXB = G::PXB, RPB = G::RPB;
   constexpr int PLANE_B = G::PLANE_B, ABUF_B = G::ABUF_B, BOFF = G::BOFF, SLOT_B = G::SLOT_B;
   constexpr int ITEMS = G::ITEMS, NT = G::NT, NST = G::NST;
   static_assert(NST == 3 || NST == 4, "staging passes");
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
   const int li = lane & 31, lh = lane >> 5;
 
   int tile;
-  {
+  {  // XCD-aware order: blocks with equal id mod 8 share an XCD (speed only) -> give each XCD a contiguous tile range
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
   const float out_scale = reinterpret_cast<const float*>(g.wpack)[1] * __uint_as_float((unsigned)(127 - ea) << 23);
 
   // ---- staging descriptors: item i = tid + 512 j -> (halo pixel i >> 2, float4 i & 3); invariant over chunks
-  int goff[NST], sdst[NST];
+  int goff[NST], sdst[NST], ssoff[NST];
   unsigned vmask = 0u;
 #pragma unroll
   for (int j = 0; j < NST; ++j) {
@@ -115,7 +122,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
     const bool ok = (i < ITEMS) && ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
     goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
     sdst[j] = (i < ITEMS) ? (nl * HR + hy) * RPB + hx * PXB + c4 * 8 : -1;
+    ssoff[j] = (nl < NI ? nl : 0) * Cin + c4 * 4;
     vmask |= (ok ? 1u : 0u) << j;
+  }
+  // pre-op coefficients of the tile's images: [scale | shift][NI][Cin] floats behind the weight ring
+  float* ss = reinterpret_cast<float*>(smem + G::LDS_B);
+  if constexpr (PRE) {
+    for (int i = tid; i < NI * Cin; i += NT) {
+      const int nl = i / Cin, ch = i - nl * Cin;
+      ss[i] = g.pre_scale[(size_t)(img0 + nl) * Cin + ch];
+      ss[NI * Cin + i] = g.pre_shift[(size_t)(img0 + nl) * Cin + ch];
+    }
+    __syncthreads();
   }
 
   // halo loads are inline asm: hipcc must not count them (beside LDS-DMA it would drain vmcnt to 0 at their first use);
@@ -137,16 +155,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
     else                                                                                                         \
       asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[NST - 1])::"memory"); \
   } while (0)
-  auto stage_store = [&](int buf) {
+  auto stage_store = [&](int buf, int c) {  // c: the chunk in the staging registers
     char* dst = smem + buf * ABUF_B;
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
       if (sdst[j] < 0) continue;
       const bool ok = (vmask >> j) & 1u;
+      f32x4v v = stg[j];
+      if constexpr (PRE) {
+        const f32x4v sc = *reinterpret_cast<const f32x4v*>(ss + ssoff[j] + c * 16);
+        const f32x4v sh = *reinterpret_cast<const f32x4v*>(ss + NI * Cin + ssoff[j] + c * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = swish_fast(v[e] * sc[e] + sh[e]);
+      }
       f16x4_t h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float X = ok ? stg[j][e] * sa : 0.f;
+        const float X = ok ? v[e] * sa : 0.f;
         const _Float16 hh = (_Float16)X;
         h[e] = hh;
         l[e] = (_Float16)(X - (float)hh);
@@ -206,13 +231,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   auto mfma12 = [&](const Frags& f) {
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #define FL_PIECE(pa, pb)                                                                         \
     _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) \
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm][pa], f.b[tn][pb], acc[tm][tn], 0, 0, 0);
     FL_PIECE(1, 0) FL_PIECE(0, 1) FL_PIECE(0, 0)  // l*h, h*l, h*h: smallest terms first
 #undef FL_PIECE
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- prologue: chunk 0 staged, taps 0..2 of chunk 0 in the ring, fragments of tap 0 in registers
@@ -221,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
   dma_tap(0, 1, 1);
   dma_tap(0, 2, 2);
   FL_STAGE_WAIT(3);
-  stage_store(0);
+  stage_store(0, 0);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -250,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
     } else {
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     }
-    if constexpr (T == 3) stage_store((c + 1) & 1);  // the other buffer: last read while tap 7 of the previous chunk ran
+    if constexpr (T == 3) stage_store((c + 1) & 1, c + 1 < nC ? c + 1 : c);  // the other buffer: last read while tap 7 of the previous chunk ran
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) as a builtin: hipcc then knows the fragment reads have landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -280,6 +305,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
 
   // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
   float st1[2], st2[2], bv[2];
+  const bool has_act = g.act != FL_ACT_NONE;
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) {
     st1[tn] = st2[tn] = 0.f;
@@ -293,7 +319,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
       float* yrow = g.y + (size_t)m * g.Cout + tile_n0 + wc * 64 + li;
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
-        const float v = fl::apply_act(acc[tm][tn][e] * out_scale + bv[tn], g.act, g.act_param);
+        float v = acc[tm][tn][e] * out_scale + bv[tn];
+        if (has_act) v = fl::apply_act(v, g.act, g.act_param);  // wave-uniform; the encoder's convs have none
         yrow[tn * 32] = v;
         st1[tn] += v;
         st2[tn] += v * v;
@@ -341,10 +368,10 @@ struct H2Geom4 {
   static_assert(LDS_B <= 160 * 1024, "LDS");
 };
 
-template <int WO, int PRIO>
+template <int WO, int PRE>
 __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
   using G = H2Geom4<WO>;
-  constexpr int BM = G::BM, BN = G::BN, W = G::W, RI = G::RI, HR = G::HR, HC = G::HC, PXB = G::PXB, RPB = G::RPB;
+  constexpr int BM = G::BM, BN = G::BN, W = G::W, RI = G::RI, NI = G::NI, HR = G::HR, HC = G::HC, PXB = G::PXB, RPB = G::RPB;
   constexpr int PAR_B = G::PAR_B, PLANE_B = G::PLANE_B, ABUF_B = G::ABUF_B, BOFF = G::BOFF, SLOT_B = G::SLOT_B;
   constexpr int ITEMS = G::ITEMS, NT = G::NT, NST = G::NST;
   static_assert(NST == 5 || NST == 6, "staging passes");
@@ -355,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
   const int li = lane & 31, lh = lane >> 5;
 
   int tile;
-  {
+  {  // XCD-aware order: blocks with equal id mod 8 share an XCD (speed only) -> give each XCD a contiguous tile range
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
@@ -371,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
   const float out_scale = reinterpret_cast<const float*>(g.wpack)[1] * __uint_as_float((unsigned)(127 - ea) << 23);
 
   // ---- staging descriptors: item i = tid + 512 j -> (halo pixel i >> 1, float4 i & 1)
-  int goff[NST], sdst[NST];
+  int goff[NST], sdst[NST], ssoff[NST];
   unsigned vmask = 0u;
 #pragma unroll
   for (int j = 0; j < NST; ++j) {
@@ -383,7 +410,17 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
     const bool ok = (i < ITEMS) && ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
     goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
     sdst[j] = (i < ITEMS) ? (hx & 1) * PAR_B + (nl * HR + hy) * RPB + (hx >> 1) * PXB + c4 * 8 : -1;
+    ssoff[j] = (nl < NI ? nl : 0) * Cin + c4 * 4;
     vmask |= (ok ? 1u : 0u) << j;
+  }
+  float* ss = reinterpret_cast<float*>(smem + G::LDS_B);
+  if constexpr (PRE) {
+    for (int i = tid; i < NI * Cin; i += NT) {
+      const int nl = i / Cin, ch = i - nl * Cin;
+      ss[i] = g.pre_scale[(size_t)(img0 + nl) * Cin + ch];
+      ss[NI * Cin + i] = g.pre_shift[(size_t)(img0 + nl) * Cin + ch];
+    }
+    __syncthreads();
   }
 
   f32x4v stg[NST];
@@ -403,16 +440,23 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
       asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                 \
                    : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[NST - 1])::"memory");      \
   } while (0)
-  auto stage_store = [&](int buf) {
+  auto stage_store = [&](int buf, int c) {  // c: the chunk in the staging registers
     char* dst = smem + buf * ABUF_B;
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
       if (sdst[j] < 0) continue;
       const bool ok = (vmask >> j) & 1u;
+      f32x4v v = stg[j];
+      if constexpr (PRE) {
+        const f32x4v sc = *reinterpret_cast<const f32x4v*>(ss + ssoff[j] + c * 8);
+        const f32x4v sh = *reinterpret_cast<const f32x4v*>(ss + NI * Cin + ssoff[j] + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = swish_fast(v[e] * sc[e] + sh[e]);
+      }
       f16x4_t h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float X = ok ? stg[j][e] * sa : 0.f;
+        const float X = ok ? v[e] * sa : 0.f;
         const _Float16 hh = (_Float16)X;
         h[e] = hh;
         l[e] = (_Float16)(X - (float)hh);
@@ -470,13 +514,13 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   auto mfma12 = [&](const Frags& f) {
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #define FL_PIECE(pa, pb)                                                                         \
     _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) \
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm][pa], f.b[tn][pb], acc[tm][tn], 0, 0, 0);
     FL_PIECE(1, 0) FL_PIECE(0, 1) FL_PIECE(0, 0)
 #undef FL_PIECE
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- prologue: chunk 0 staged, k groups 0..3 in the ring, fragments of group 0 in registers
@@ -486,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
   dma_grp(0, 2, 2);
   dma_grp(0, 3, 3);
   FL_STAGE_WAIT4(4);
-  stage_store(0);
+  stage_store(0, 0);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -517,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
     } else {
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     }
-    if constexpr (T == 4) stage_store((c + 1) & 1);  // the other buffer: last read while group 6 of the previous chunk ran
+    if constexpr (T == 4) stage_store((c + 1) & 1, c + 1 < nC ? c + 1 : c);  // the other buffer: last read while group 6 of the previous chunk ran
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -539,6 +583,7 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   float st1[2], st2[2], bv[2];
+  const bool has_act = g.act != FL_ACT_NONE;
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) {
     st1[tn] = st2[tn] = 0.f;
@@ -552,7 +597,8 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
       float* yrow = g.y + (size_t)m * g.Cout + tile_n0 + wc * 64 + li;
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
-        const float v = fl::apply_act(acc[tm][tn][e] * out_scale + bv[tn], g.act, g.act_param);
+        float v = acc[tm][tn][e] * out_scale + bv[tn];
+        if (has_act) v = fl::apply_act(v, g.act, g.act_param);  // wave-uniform; the encoder's convs have none
         yrow[tn * 32] = v;
         st1[tn] += v;
         st2[tn] += v * v;
@@ -622,10 +668,10 @@ __global__ void h2_pack_kernel(const float* __restrict__ w, char* __restrict__ o
 
 template <int W>
 void h2_set_attr() {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, H2Geom<W>::LDS_B);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, H2Geom<W>::LDS_B);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, H2Geom4<W>::LDS_B);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, H2Geom4<W>::LDS_B);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 }  // namespace
@@ -646,27 +692,44 @@ bool conv4x4s2_h2_applicable(const float* x, int B, int H, int W, int Cin, int C
   return false;
 }
 
+// bytes of the pre-op coefficient block ([scale | shift][images per tile][Cin]) behind the kernel's static LDS layout
+static int h2_pre_bytes(int ksize, int Wout, int Cin) {
+  const int ni = (256 / Wout) > Wout ? (256 / Wout) / Wout : 1;
+  return 2 * ni * Cin * (int)sizeof(float);
+}
+
+int conv_h2_lds_bytes(int ksize, int Win, int Cin, bool pre) {
+  const int Wout = ksize == 3 ? Win : Win / 2;
+  int base;
+  if (ksize == 3) base = Wout == 32 ? H2Geom<32>::LDS_B : (Wout == 16 ? H2Geom<16>::LDS_B : H2Geom<8>::LDS_B);
+  else base = Wout == 32 ? H2Geom4<32>::LDS_B : (Wout == 16 ? H2Geom4<16>::LDS_B : H2Geom4<8>::LDS_B);
+  return base + (pre ? h2_pre_bytes(ksize, Wout, Cin) : 0);
+}
+
 int launch_conv_h2(const float* x, const void* wpack, const float* bias, float* y, float* stats, const unsigned* a_amax,
-                   int a_exp, int B, int H, int W, int Cin, int Cout, int ksize, int act, float act_param, hipStream_t s) {
+                   int a_exp, const float* pre_scale, const float* pre_shift, int B, int H, int W, int Cin, int Cout, int ksize,
+                   int act, float act_param, hipStream_t s) {
   H2Args g;
+  g.pre_scale = pre_scale; g.pre_shift = pre_shift;
+  const int pre_b = pre_scale ? h2_pre_bytes(ksize, ksize == 3 ? W : W / 2, Cin) : 0;
   g.x = x; g.wpack = reinterpret_cast<const char*>(wpack); g.bias = bias; g.y = y; g.stats = stats;
   g.a_amax = a_amax; g.a_exp = a_exp;
   g.Cin = Cin; g.Cout = Cout; g.tiles_n = Cout / 128; g.act = act; g.act_param = act_param;
   g.M = ksize == 3 ? B * H * W : B * (H / 2) * (W / 2);
-  const int blocks = (g.M / 256) * g.tiles_n;
+  g.ntiles = (g.M / 256) * g.tiles_n;
+  const int blocks = g.ntiles;
   static std::once_flag once;
   std::call_once(once, [] { h2_set_attr<32>(); h2_set_attr<16>(); h2_set_attr<8>(); });
-  static int prio = -1;
-  if (prio < 0) { const char* e = getenv("FL_H2_PRIO"); prio = e ? atoi(e) : 1; }
+  const int prio = g.pre_scale != nullptr;  // template PRE
 #define FL_LAUNCH(WW)                                                                                              \
   do {                                                                                                             \
-    if (prio) hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 1>), dim3(blocks), dim3(512), H2Geom<WW>::LDS_B, s, g);    \
-    else hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 0>), dim3(blocks), dim3(512), H2Geom<WW>::LDS_B, s, g);         \
+    if (prio) hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 1>), dim3(blocks), dim3(512), H2Geom<WW>::LDS_B + pre_b, s, g);    \
+    else hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 0>), dim3(blocks), dim3(512), H2Geom<WW>::LDS_B + pre_b, s, g);         \
   } while (0)
 #define FL_LAUNCH4(WW)                                                                                               \
   do {                                                                                                             \
-    if (prio) hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 1>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B, s, g);  \
-    else hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 0>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B, s, g);       \
+    if (prio) hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 1>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B + pre_b, s, g);  \
+    else hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 0>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B + pre_b, s, g);       \
   } while (0)
   if (ksize == 3) {
     if (W == 32) FL_LAUNCH(32);
@@ -718,8 +781,10 @@ int fl_conv2d_fwd_f16x2_applicable(const float* x, int B, int H, int W, int Cin,
 int fl_conv2d_fwd_f16x2(const float* x, const void* wpack, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                         int kh, int kw, int stride, int pad, int act, float act_param, const float* ln_w, const float* ln_b,
                         float eps, float* scale, float* shift, float* mean, float* rstd, const float* x_amax, int x_exp,
-                        void* ws, size_t ws_bytes, fl_stream_t stream) {
+                        const float* pre_scale, const float* pre_shift, void* ws, size_t ws_bytes, fl_stream_t stream) {
   FL_REQUIRE(x && wpack && y, "fl_conv2d_fwd_f16x2: null operand");
+  FL_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr), "fl_conv2d_fwd_f16x2: pre_scale / pre_shift come together");
+  FL_REQUIRE(fl::conv_h2_lds_bytes(kh, W, Cin, pre_scale != nullptr) <= 160 * 1024, "fl_conv2d_fwd_f16x2: Cin %d too large for the fused pre-op", Cin);
   FL_REQUIRE(fl_conv2d_fwd_f16x2_applicable(x, B, H, W, Cin, Cout, kh, kw, stride, pad),
              "fl_conv2d_fwd_f16x2: unsupported shape (B=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d)", B, H, W, Cin, Cout, kh, kw, stride, pad);
   FL_REQUIRE(x_exp >= -100 && x_exp <= 100, "fl_conv2d_fwd_f16x2: x_exp %d out of range", x_exp);
@@ -732,8 +797,8 @@ int fl_conv2d_fwd_f16x2(const float* x, const void* wpack, const float* bias, fl
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float* part = stats ? reinterpret_cast<float*>(ws) : nullptr;
-  const int rc = fl::launch_conv_h2(x, wpack, bias, y, part, reinterpret_cast<const unsigned*>(x_amax), x_exp, B, H, W, Cin, Cout, kh,
-                                    act, act_param, s);
+  const int rc = fl::launch_conv_h2(x, wpack, bias, y, part, reinterpret_cast<const unsigned*>(x_amax), x_exp, pre_scale, pre_shift, B, H,
+                                    W, Cin, Cout, kh, act, act_param, s);
   if (rc || !stats) return rc;
   return fl::launch_conv_inorm_finalize(part, ln_w, ln_b, eps, scale, shift, mean, rstd, B, HW, Cout, HW / 64, s);
 }

@@ -100,7 +100,9 @@ int launch_conv_inorm_finalize(const float* partial, const float* ln_w, const fl
 bool conv3x3_h2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 bool conv4x4s2_h2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 int launch_conv_h2(const float* x, const void* wpack, const float* bias, float* y, float* stats, const unsigned* a_amax,
-                   int a_exp, int B, int H, int W, int Cin, int Cout, int ksize, int act, float act_param, hipStream_t s);
+                   int a_exp, const float* pre_scale, const float* pre_shift, int B, int H, int W, int Cin, int Cout, int ksize,
+                   int act, float act_param, hipStream_t s);
+int conv_h2_lds_bytes(int ksize, int Win, int Cin, bool pre);
 size_t pack_weight_f16x2_bytes(int N, int K);
 int pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, hipStream_t s);
 

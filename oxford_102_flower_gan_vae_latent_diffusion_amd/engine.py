@@ -72,17 +72,28 @@ def _d(p):
     return p.detach() if p is not None else None
 
 
-def conv_ln_infer(x, conv, ln, stride, pad, pk, x_bound=None):
+def _f16x2_usable(x, conv, stride, pad, x_bound):
+    Cout, _, kh, kw = conv.weight.shape
+    return (USE_F16X2 and x_bound is not None and ops.get_gemm_math() == "split"
+            and ops.f16x2_ok(x, Cout, kh, kw, stride, pad))
+
+
+def conv_ln_infer(x, conv, ln, stride, pad, pk, x_bound=None, pre=None):
     """inference conv + fused LayerNorm2d statistics -> (y, scale, shift); weights pre-split when the layer qualifies.
-    x_bound: (1,) device float >= max|x| (PackCache.ln_bound) - enables the f16x2 kernel for the 3x3 convs."""
+    x_bound: (1,) device float >= max|input| (PackCache.ln_bound) - enables the f16x2 kernels.
+    pre = (scale, shift): the conv's input is swish(x * scale[b,c] + shift[b,c]) - fused into the f16x2 kernels' halo
+    staging, materialised by fl_affine_act for the others."""
     B, H, W, Cin = x.shape
     Cout, _, kh, kw = conv.weight.shape
     Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-    if ops.get_gemm_math() == "split" and x_bound is not None and USE_F16X2 and ops.f16x2_ok(x, Cout, kh, kw, stride, pad):
+    if _f16x2_usable(x, conv, stride, pad, x_bound):
         wh, geom = pk.conv_h2(conv)
         y, (sc, sh, _, _) = ops.conv2d_fwd_f16x2(x, wh, geom, _d(conv.bias), stride, pad, ln_w=_d(ln.weight), ln_b=_d(ln.bias),
-                                                 eps=ln.eps, x_amax=x_bound)
-    elif ops.get_gemm_math() == "split" and ops.presplit_ok(Cin, Cout, Ho * Wo):
+                                                 eps=ln.eps, x_amax=x_bound, pre=pre)
+        return y, sc, sh
+    if pre is not None:
+        x = ops.affine_act(x, pre[0], pre[1], act=SW)
+    if ops.get_gemm_math() == "split" and ops.presplit_ok(Cin, Cout, Ho * Wo):
         ws, geom = pk.conv_split(conv)
         y, (sc, sh, _, _) = ops.conv2d_fwd_presplit(x, ws, geom, _d(conv.bias), stride, pad, ln_w=_d(ln.weight),
                                                     ln_b=_d(ln.bias), eps=ln.eps)
@@ -101,20 +112,26 @@ def ca_gate(ca, pooled):
     return ops.linear(h, w2, None, act=ops.ACT_SIGMOID)
 
 
-def resblock_infer(x, rb, pk, x_bound=None):
-    """ResidualBlock.forward (v2:170-178), NHWC, no saved state. 2 convs + 2 stats passes + 3 streaming passes.
-    x_bound: (1,) device float >= max|x| or None (then the range-agnostic bf16x3 conv kernels run)."""
+def resblock_infer(x, rb, pk, x_bound=None, x_pre=None):
+    """ResidualBlock.forward (v2:170-178), NHWC, no saved state.
+    x_bound: (1,) device float >= max|block input| or None (then the range-agnostic bf16x3 conv kernels run).
+    x_pre = (scale, shift): the block input is swish(x * scale[b,c] + shift[b,c]) and is never materialised - conv1
+    applies it while staging, the residual add re-applies it (engine.encoder_infer hands the down conv's raw output)."""
     HW = x.shape[1] * x.shape[2]
-    y1, sc, sh = conv_ln_infer(x, rb.conv1, rb.ln1, 1, 1, pk, x_bound)
-    a1 = ops.affine_act(y1, sc, sh, act=SW, out=y1)
-    y2, sc2, sh2 = conv_ln_infer(a1, rb.conv2, rb.ln2, 1, 1, pk, pk.ln_bound(rb.ln1, HW) if x_bound is not None else None)
+    y1, sc, sh = conv_ln_infer(x, rb.conv1, rb.ln1, 1, 1, pk, x_bound, x_pre)
+    b1 = pk.ln_bound(rb.ln1, HW) if x_bound is not None else None
+    if _f16x2_usable(y1, rb.conv2, 1, 1, b1):  # LayerNorm2d-apply + Swish of v2:163-164 fused into conv2's staging
+        y2, sc2, sh2 = conv_ln_infer(y1, rb.conv2, rb.ln2, 1, 1, pk, b1, (sc, sh))
+    else:
+        a1 = ops.affine_act(y1, sc, sh, act=SW, out=y1)
+        y2, sc2, sh2 = conv_ln_infer(a1, rb.conv2, rb.ln2, 1, 1, pk, b1)
     # avg_pool(LayerNorm2d(y)) == ln2.bias exactly (normalised maps have zero spatial mean), so the
     # channel-attention gate (v2:65-66) is one (C,) vector shared by the batch: no pooling pass.
     # ... and a function of the weights only: computed once per weight version, not per batch.
     s = pk.get(("cagate", id(rb)), [rb.ca.conv_du[0].weight, rb.ca.conv_du[2].weight, rb.ln2.bias],
                lambda: ca_gate(rb.ca, _d(rb.ln2.bias).view(1, -1)).view(-1))
     m = ops.res_tail_map(y2, sc2, sh2, s)
-    return ops.res_tail_out(y2, sc2, sh2, s, m, _d(rb.sa.conv.weight).contiguous(), xres=x, final_swish=True)
+    return ops.res_tail_out(y2, sc2, sh2, s, m, _d(rb.sa.conv.weight).contiguous(), xres=x, final_swish=True, xres_pre=x_pre)
 
 
 def _head(fc, flat, w0=None):
@@ -124,24 +141,28 @@ def _head(fc, flat, w0=None):
     return ops.linear(g, _d(fc[3].weight), _d(fc[3].bias))
 
 
-def encoder_infer(enc, x):
-    """Encoder.forward (v2:223-239). x (B,3,64,64) NCHW -> mu, logvar (B,latent), [NHWC skip features]."""
+def encoder_infer(enc, x, want_feats=True):
+    """Encoder.forward (v2:223-239). x (B,3,64,64) NCHW -> mu, logvar (B,latent), [NHWC skip features] (v2:224-235;
+    want_feats=False: the list holds None where an activation was fused away - the decoder ignores it, v2:280)."""
     pk = enc._pk
     B = x.shape[0]
     h = ops.nchw_to_nhwc(x, 4)
     c0, ln0 = enc.initial_conv[0], enc.initial_conv[1]
     y, (sc, sh, _, _) = ops.conv2d_fwd_instnorm(h, pk.conv(c0), _d(c0.bias), 1, 1, _d(ln0.weight), _d(ln0.bias), ln0.eps)
-    h = ops.affine_act(y, sc, sh, act=SW, out=y)
-    feats = [h]
     # range information of the f16x2 convs: |swish(ln(.))| <= the LayerNorm2d bound; a ResidualBlock adds its input's bound
     bound = pk.ln_bound(ln0, y.shape[1] * y.shape[2])
+    # the LayerNorm2d-apply + Swish passes (v2:187-188, v2:193-194, ...) are fused into the consuming conv's halo staging:
+    # `h` stays the raw conv output and `pre` its (scale, shift) until something needs the activation itself
+    pre = (sc, sh)
+    h = y
+    feats = [ops.affine_act(y, sc, sh, act=SW) if want_feats else None]
     for i in (1, 2, 3):
         dn, rb = getattr(enc, "down%d" % i), getattr(enc, "res%d" % i)
-        y, sc, sh = conv_ln_infer(h, dn[0], dn[1], 2, 1, pk, bound)
+        y, sc, sh = conv_ln_infer(h, dn[0], dn[1], 2, 1, pk, bound, pre)
         HW = y.shape[1] * y.shape[2]
-        h = ops.affine_act(y, sc, sh, act=SW, out=y)
         bd = pk.ln_bound(dn[1], HW)
-        h = resblock_infer(h, rb, pk, bd)
+        h = resblock_infer(y, rb, pk, bd, (sc, sh))
+        pre = None
         bound = pk.ln_bound(rb.ln2, HW, bd)
         feats.append(h)
     # x.view(B,-1) of the NCHW tensor (v2:236): instead of transposing 33 MB of activations per batch, the columns of the

@@ -279,10 +279,12 @@ def f16x2_ok(x, Cout, kh, kw, stride, pad):
 
 
 def conv2d_fwd_f16x2(x, wpack, geom, bias, stride=1, pad=1, act=ACT_NONE, act_param=0.0, ln_w=None, ln_b=None, eps=1e-5,
-                     out=None, x_amax=None, x_exp=6):
+                     out=None, x_amax=None, x_exp=6, pre=None):
     """3x3 s1 p1 / 4x4 s2 p1 conv forward in f16x2 split math (geom = (Cout, kh, kw, Cin) of the packed weight). x_amax: device float
-    bounding max|x| (else activations are scaled by 2^x_exp). With ln_w/ln_b: also the fused LayerNorm2d statistics."""
-    _chk(x, bias, ln_w, ln_b, out, x_amax)
+    bounding max|x| (else activations are scaled by 2^x_exp). With ln_w/ln_b: also the fused LayerNorm2d statistics.
+    pre = (scale, shift) (B, Cin): the conv consumes swish(x * scale[b,c] + shift[b,c]) (x_amax bounds THAT)."""
+    ps, ph = pre if pre is not None else (None, None)
+    _chk(x, bias, ln_w, ln_b, out, x_amax, ps, ph)
     B, H, W, Cin = x.shape
     Cout, kh, kw, Ci2 = geom
     assert Ci2 == Cin
@@ -290,13 +292,14 @@ def conv2d_fwd_f16x2(x, wpack, geom, bias, stride=1, pad=1, act=ACT_NONE, act_pa
     y = out if out is not None else new((B, Ho, Wo, Cout), x)
     if ln_w is None:
         _lib.call("fl_conv2d_fwd_f16x2", _p(x), _p(wpack), _p(bias), _p(y), B, H, W, Cin, Cout, kh, kw, stride, pad, act,
-                  float(act_param), None, None, float(eps), None, None, None, None, _p(x_amax), int(x_exp), None, 0, _stream())
+                  float(act_param), None, None, float(eps), None, None, None, None, _p(x_amax), int(x_exp), _p(ps), _p(ph), None, 0,
+                  _stream())
         return y
     scale, shift, mean, rstd = (new((B, Cout), x) for _ in range(4))
     wsp, wsn = _ws(_lib.load().fl_conv2d_fwd_instnorm_workspace_bytes(B, Ho, Wo, Cout), x)
     _lib.call("fl_conv2d_fwd_f16x2", _p(x), _p(wpack), _p(bias), _p(y), B, H, W, Cin, Cout, kh, kw, stride, pad, act,
               float(act_param), _p(ln_w), _p(ln_b), float(eps), _p(scale), _p(shift), _p(mean), _p(rstd), _p(x_amax), int(x_exp),
-              wsp, wsn, _stream())
+              _p(ps), _p(ph), wsp, wsn, _stream())
     return y, (scale, shift, mean, rstd)
 
 
@@ -490,14 +493,18 @@ def res_tail_map(y, scale=None, shift=None, s=None):
     return m
 
 
-def res_tail_out(y, scale=None, shift=None, s=None, map_=None, saw=None, xres=None, final_swish=False, save_att=False):
+def res_tail_out(y, scale=None, shift=None, s=None, map_=None, saw=None, xres=None, final_swish=False, save_att=False,
+                 xres_pre=None):
+    """xres_pre = (scale, shift): the residual is swish(xres * scale[b,c] + shift[b,c]) (its norm pass is fused here)."""
     _chk(y, scale, shift, s, map_, saw, xres)
     B, H, W, C = y.shape
     out = torch.empty_like(y)
     att = new((B, H, W), y) if save_att else None
     spi = int(s is not None and s.dim() == 2)
-    _lib.call("fl_res_tail_out", _p(y), _p(scale), _p(shift), _p(s), spi, _p(map_), _p(saw), _p(xres), _p(out), _p(att),
-              B, H, W, C, int(final_swish), _stream())
+    xs, xh = xres_pre if xres_pre is not None else (None, None)
+    _chk(xs, xh)
+    _lib.call("fl_res_tail_out_pre", _p(y), _p(scale), _p(shift), _p(s), spi, _p(map_), _p(saw), _p(xres), _p(xs), _p(xh), _p(out),
+              _p(att), B, H, W, C, int(final_swish), _stream())
     return (out, att) if save_att else out
 
 

@@ -151,7 +151,7 @@ class DDPMTrainer:
     @torch.no_grad()
     def encode(self, data, reparam_eps=None):
         """v2:1257-1259 (frozen encoder, eval)."""
-        mu, logvar, _ = engine.encoder_infer(self.ae.encoder, data)
+        mu, logvar, _ = engine.encoder_infer(self.ae.encoder, data, want_feats=False)
         if reparam_eps is None:
             reparam_eps = self.ae.rng.normal(mu.shape, mu.device)
         z, _ = ops.reparameterize(mu, logvar, reparam_eps)

@@ -71,14 +71,25 @@ def main():
         ys0 = ops.conv2d_fwd_presplit(xs, wsp, geom, None, s, p)
         ys1 = ops.conv2d_fwd_f16x2(xs, wh2, geom, None, s, p)
         dsub = (ys0 - ys1).abs().max().item() / ys0.abs().max().item()
-        nan = bool(torch.isnan(y1).any().item())
+        # fused pre-op: conv(swish(x*sc+sh)) with the LayerNorm2d-apply inside the halo staging vs materialised by fl_affine_act
+        gsc = torch.rand(B, Ci, generator=g) + 0.5
+        gsh = torch.randn(B, Ci, generator=g) * 0.3
+        scd, shd = gsc.to(dev), gsh.to(dev)
+        xa = ops.affine_act(xd, scd, shd, act=ops.ACT_SWISH)
+        bnd = xa.abs().max().reshape(1)
+        yp0 = ops.conv2d_fwd_f16x2(xa, wh2, geom, bd, s, p, x_amax=bnd)
+        yp1 = ops.conv2d_fwd_f16x2(xd, wh2, geom, bd, s, p, x_amax=bnd, pre=(scd, shd))
+        dpre = (yp0 - yp1).abs().max().item() / yp0.abs().max().item()
+        nan = bool(torch.isnan(y1).any().item()) or bool(torch.isnan(yp1).any().item()) or dpre > 3e-6
         good = d01 / sc < 6e-6 and e1 < 1.5 * e0 + 1e-7 and e2 < 1.5 * e0 + 1e-7 and ds < 1e-5 and dsub < 1e-5 and not nan
         ok_all &= good
         print("%dx%d s%d H=%2d Ci=%3d Co=%3d  |bf16x3-f16x2|/max %.2e  |static-amax| %.2e  err vs fp64: bf16x3 %.2e f16x2 %.2e (amax %.2e)"
-              "  stats %.2e  tiny-x %.2e  %s" % (k, k, s, H, Ci, Co, d01 / sc, d12 / sc, e0, e1, e2, ds, dsub, "OK" if good else "FAIL"), flush=True)
+              "  stats %.2e  tiny-x %.2e  pre-op %.2e  %s" % (k, k, s, H, Ci, Co, d01 / sc, d12 / sc, e0, e1, e2, ds, dsub, dpre, "OK" if good else "FAIL"), flush=True)
         fl = 2.0 * B * Ho * Ho * Co * k * k * Ci
+        tot.setdefault("f16x2 + pre-op", 0.0)
         for name, run in (("bf16x3 halo", lambda: ops.conv2d_fwd_presplit(xd, wsp, geom, bd, s, p, out=y0)),
-                          ("f16x2", lambda: ops.conv2d_fwd_f16x2(xd, wh2, geom, bd, s, p, out=y1, x_amax=amax))):
+                          ("f16x2", lambda: ops.conv2d_fwd_f16x2(xd, wh2, geom, bd, s, p, out=y1, x_amax=amax)),
+                          ("f16x2 + pre-op", lambda: ops.conv2d_fwd_f16x2(xd, wh2, geom, bd, s, p, out=y1, x_amax=bnd, pre=(scd, shd)))):
             for _ in range(5):
                 run()
             e_0, e_1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -90,7 +101,8 @@ def main():
             ms = e_0.elapsed_time(e_1) / reps
             tot[name] += ms * mult
             print("    %-12s %8.4f ms  %7.1f TFLOP/s fp32-equivalent" % (name, ms, fl / ms / 1e9), flush=True)
-    print("nine encoder convs: bf16x3 halo %.3f ms, f16x2 %.3f ms" % (tot["bf16x3 halo"], tot["f16x2"]))
+    print("nine encoder convs: bf16x3 halo %.3f ms, f16x2 %.3f ms, f16x2 with fused LayerNorm2d-apply + Swish %.3f ms"
+          % (tot["bf16x3 halo"], tot["f16x2"], tot["f16x2 + pre-op"]))
     print("ALL OK" if ok_all else "SOME FAILED")
     return 0 if ok_all else 1
 
