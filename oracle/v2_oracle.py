@@ -381,18 +381,21 @@ def ddpm_step(ae_sd, unet_sd, data, labels, reparam_eps, t, eps, lr=1e-3, block_
 
 def vae_gan_step(ae_sd, d_sd, vgg_sd, data, labels, reparam_eps, epoch=200, num_epochs=300, lr=1e-4,
                  lambda_cls=0.1, lambda_center=0.05, lambda_vgg=0.4, lambda_gan=0.2, cls_masks=(None, None),
-                 ae_opt_state=None, d_opt_state=None):
+                 ae_opt_state=None, d_opt_state=None, ae_beta1=0.9):
     """One iteration of train_autoencoder's loop body v2:1060-1134 (explicit reparam noise; classifier
     dropout masks explicit). Order of operations, the D-update-before-G-adversarial ordering (v2:1097-1105),
-    the detached loss-balancing scales (v2:1107-1115) and the optimizers (v2:1026-1028) follow the reference."""
+    the detached loss-balancing scales (v2:1107-1115) and the optimizers (v2:1026-1028) follow the reference.
+    lr / ae_beta1: what OneCycleLR (v2:1031-1037; it cycles AdamW's beta1 too) has set for this step."""
     ae = _params(ae_sd)
     dd = _params(d_sd)
     ae_names = [k for k, v in ae.items() if v.requires_grad]
     d_names = [k for k, v in dd.items() if v.requires_grad]
-    opt = torch.optim.AdamW([ae[k] for k in ae_names], lr=lr, weight_decay=1e-5, betas=(0.9, 0.999))
+    opt = torch.optim.AdamW([ae[k] for k in ae_names], lr=lr, weight_decay=1e-5, betas=(ae_beta1, 0.999))
     d_opt = torch.optim.Adam([dd[k] for k in d_names], lr=1e-4, betas=(0.5, 0.999))
     if ae_opt_state is not None:
         opt.load_state_dict(ae_opt_state)
+        for gp in opt.param_groups:
+            gp["lr"], gp["betas"] = lr, (ae_beta1, 0.999)
     if d_opt_state is not None:
         d_opt.load_state_dict(d_opt_state)
     kl_weight = kl_weight_at(epoch, num_epochs)

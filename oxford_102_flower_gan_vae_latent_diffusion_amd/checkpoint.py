@@ -47,31 +47,55 @@ def _rngs(*objs):
     for name, o in objs:
         r = getattr(o, "rng", None)
         if r is not None:
-            out[name] = {"seed": r.seed, "state": {str(k): v.detach().cpu() for k, v in r._state.items()}}
+            out[name] = {"seed": r.seed, "state": {"%s:%s" % k: v.detach().cpu() for k, v in r._state.items()}}
     return out
 
 
-def save_train_state(path, trainer):
-    """Side-car with everything needed for a bit-exact resume of a DDPMTrainer."""
-    opt = trainer.opt
-    torch.save({"m": opt.m.detach().cpu(), "v": opt.v.detach().cpu(), "step": opt.step_count.detach().cpu(),
-                "lr": opt.lr.detach().cpu(),
-                "rng": _rngs(("ae", trainer.ae), ("unet", trainer.unet), ("diffusion", trainer.diffusion))}, path)
-
-
-def load_train_state(path, trainer):
-    st = torch.load(path, map_location="cpu")
-    opt = trainer.opt
-    opt.m.copy_(st["m"])
-    opt.v.copy_(st["v"])
-    opt.step_count.copy_(st["step"])
-    opt.lr.copy_(st["lr"])
-    for name, o in (("ae", trainer.ae), ("unet", trainer.unet), ("diffusion", trainer.diffusion)):
-        info = st["rng"].get(name)
-        if info is None:
+def _load_rngs(saved, dev, *objs):
+    """Philox counters are per device: restore each one onto the device it was saved for (a state saved for 'cuda:i' goes
+    to `dev` when it is a cuda device - one process per GPU, the index may differ after a resume)."""
+    dev = torch.device(dev)
+    for name, o in objs:
+        info = saved.get(name)
+        r = getattr(o, "rng", None)
+        if info is None or r is None:
             continue
-        o.rng.seed = info["seed"]
-        dev = next(iter(trainer.unet.parameters())).device
-        for _, v in info["state"].items():
-            o.rng.state(dev).copy_(v)
+        r.seed = info["seed"]
+        for key, v in info["state"].items():
+            kind = str(key).split(":")[0].strip("(' ")
+            if kind == dev.type or ("cuda" in kind and dev.type == "cuda"):
+                r.state(dev).copy_(v)
+            elif kind == "cpu":
+                r.state("cpu").copy_(v)
+
+
+def save_train_state(path, trainer, scheduler=None, extra=None):
+    """Side-car with everything the reference checkpoint omits, for a bit-exact resume: optimizer moments / step / lr
+    (both optimizers of a VAEGANTrainer), the LR-schedule position and the Philox counters. Works for DDPMTrainer and
+    VAEGANTrainer (the class centres and BatchNorm buffers travel in the state-dicts, checkpoint.save_vae_gan)."""
+    st = {"opt": trainer.opt.state_dict(), "extra": extra}
+    if hasattr(trainer, "d_opt"):
+        st["kind"] = "vaegan"
+        st["d_opt"] = trainer.d_opt.state_dict()
+        st["rng"] = _rngs(("ae", trainer.ae), ("disc", trainer.disc), ("vgg", trainer.vgg))
+    else:
+        st["kind"] = "ddpm"
+        st["rng"] = _rngs(("ae", trainer.ae), ("unet", trainer.unet), ("diffusion", trainer.diffusion))
+    if scheduler is not None:
+        st["scheduler"] = scheduler.state_dict()
+    torch.save(st, path)
+
+
+def load_train_state(path, trainer, scheduler=None):
+    st = torch.load(path, map_location="cpu", weights_only=False)
+    if "opt" not in st:  # round-1 side-car layout (DDPM only)
+        st = {"kind": "ddpm", "opt": {k: st[k] for k in ("m", "v", "step", "lr")}, "rng": st.get("rng", {})}
+    trainer.opt.load_state_dict(st["opt"])
+    if st["kind"] == "vaegan":
+        trainer.d_opt.load_state_dict(st["d_opt"])
+        _load_rngs(st["rng"], trainer.dev, ("ae", trainer.ae), ("disc", trainer.disc), ("vgg", trainer.vgg))
+    else:
+        _load_rngs(st["rng"], trainer.dev, ("ae", trainer.ae), ("unet", trainer.unet), ("diffusion", trainer.diffusion))
+    if scheduler is not None and "scheduler" in st:
+        scheduler.load_state_dict(st["scheduler"])  # re-applies lr (and beta1) for the restored position
     return st

@@ -61,18 +61,23 @@ __device__ __forceinline__ Split3 split3(const float4& q0, const float4& q1) {
     t.h[p] = t.m[p] = t.l[p] = __builtin_amdgcn_perm(__float_as_uint(x[2 * p + 1]), __float_as_uint(x[2 * p]), 0x07060302u);
   return t;
 #endif
-  float r1[8], r2[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xFFFF0000u);    // exact: the low 16 mantissa bits
-    r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xFFFF0000u);  // exact: at most 8 significant bits left
-  }
+  // round-to-nearest pieces (v_cvt_pk_bf16_f32): h = rn(x), m = rn(x - h), l = rn(x - h - m). x - h and x - h - m are exact
+  // in fp32; the pieces' signs alternate, so what the 6-product scheme drops (m*l, l*m, l*l <= 2^-26 |xy|) is unbiased -
+  // the truncating split of round 1 dropped up to 2^-23 |xy| with the sign of xy (a bias that showed up as 2-8x larger
+  // gradient errors than the native fp32 MFMA on heavily cancelling sums, tools/vaegan_grad_diag.py)
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   Split3 s;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {  // two bf16 (upper halves of two floats) per word
-    s.h[p] = __builtin_amdgcn_perm(__float_as_uint(x[2 * p + 1]), __float_as_uint(x[2 * p]), 0x07060302u);
-    s.m[p] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * p + 1]), __float_as_uint(r1[2 * p]), 0x07060302u);
-    s.l[p] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * p + 1]), __float_as_uint(r2[2 * p]), 0x07060302u);
+  for (int p = 0; p < 4; ++p) {
+    const float x0 = x[2 * p], x1 = x[2 * p + 1];
+    const bf16x2_t h = {(__bf16)x0, (__bf16)x1};
+    const float a0 = x0 - (float)h[0], a1 = x1 - (float)h[1];
+    const bf16x2_t m = {(__bf16)a0, (__bf16)a1};
+    const float b0 = a0 - (float)m[0], b1 = a1 - (float)m[1];
+    const bf16x2_t l = {(__bf16)b0, (__bf16)b1};
+    s.h[p] = __builtin_bit_cast(unsigned, h);
+    s.m[p] = __builtin_bit_cast(unsigned, m);
+    s.l[p] = __builtin_bit_cast(unsigned, l);
   }
   return s;
 }

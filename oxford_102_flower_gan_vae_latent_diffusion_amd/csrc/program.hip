@@ -614,6 +614,10 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
   constexpr int TB_OFF = offsetof(fl_pjob, tile_begin) / 4;
   const unsigned G = gridDim.x;
   bool alive = true;
+  // a run that timed out left the abort word set and the arrival counters un-armed: every later launch must do NOTHING
+  // (its barriers would fall through on the stale counters and the phases would compute garbage) until the host has
+  // seen the word, re-armed the counters and raised (Program.check / Program.run)
+  if (__hip_atomic_load(&sync[NCTR * CTR_STRIDE + 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
 
 #if FL_PROG_TRACE
   if (threadIdx.x == 0) g_trace = nullptr;  // the census barrier below runs before the first phase arms the trace

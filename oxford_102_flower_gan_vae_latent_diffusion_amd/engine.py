@@ -20,12 +20,16 @@ class PackCache:
 
     def __init__(self):
         self._c = {}
+        self._keep = []  # entries replaced during a graph capture (the graph may hold their pointers)
         self.epoch = 0  # bumped by optimizers that update parameters through raw pointers
 
     def get(self, key, params, fn):
         ver = tuple((p._version, p.data_ptr()) for p in params) + (self.epoch,)
         ent = self._c.get(key)
         if ent is None or ent[0] != ver:
+            if ent is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                # a hipGraph being captured may already read the entry this one replaces: keep it alive with the cache
+                self._keep.append(ent)
             with torch.no_grad():
                 ent = (ver, fn())
             self._c[key] = ent

@@ -16,6 +16,7 @@ ACT_NONE, ACT_SWISH, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 KC, KS = 0, 1
 
 _workspaces = {}
+_retired = []  # superseded scratch buffers (kept alive: graphs captured before the growth still write into them)
 _ws_slot = 0
 
 
@@ -60,6 +61,8 @@ def workspace(nbytes, device=None):
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("workspace would grow during graph capture; run a warm-up step first")
+        if ws is not None:
+            _retired.append(ws)  # a captured hipGraph may have the old pointer baked in: never hand it back to the allocator
         ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device="cuda:%d" % device[0])
         _workspaces[device] = ws
     return ws

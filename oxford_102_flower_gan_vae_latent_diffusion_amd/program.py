@@ -184,6 +184,7 @@ class Program:
         self.phases, self.jobs, self.n_phases, self.n_jobs, self.max_tiles = phases, jobs, n_phases, n_jobs, max_tiles
         self._keep = keep
         self.sync = torch.zeros(lib.load().fl_program_sync_bytes() // 4, dtype=torch.int32, device=device)
+        self._abort_host = torch.zeros(1, dtype=torch.int32).pin_memory() if str(device).startswith("cuda") else None
         self.max_blocks = 0  # 0 = one block per CU
         self.local_ok = False  # every job works on the same batch rows: XCD-local execution is legal
         self.local = False     # FL_PROG_XCD_LOCAL requested (only honoured by the builder when local_ok)
@@ -205,14 +206,21 @@ class Program:
                     assert t.dtype == torch.int32
                     pp["ptr32"], pp["delta32"] = t.data_ptr(), d
             pbuf = ctypes.c_char_p(pp.tobytes())
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing and self._abort_host is not None and int(self._abort_host[0]) != 0:
+            self.check()  # an earlier run timed out (seen through the pinned mirror, no sync): re-arm and raise
         lib.call("fl_program_run", ctypes.c_void_p(self.phases.data_ptr()), ctypes.c_void_p(self.jobs.data_ptr()),
                  self.n_phases, self.n_jobs, arr, len(io), ctypes.c_void_p(self.sync.data_ptr()), self.max_blocks,
                  1 if self.local else 0, pbuf, ops._stream())
+        if not capturing and self._abort_host is not None:  # cheap health check: async mirror of the abort word, read next call
+            self._abort_host.copy_(self.sync[SYNC_ABORT_WORD:SYNC_ABORT_WORD + 1], non_blocking=True)
 
     def check(self):
         """Synchronising health check: raises if a barrier timed out (and re-arms the counters)."""
         if int(self.sync[SYNC_ABORT_WORD]) != 0:
             self.sync.zero_()
+            if self._abort_host is not None:
+                self._abort_host.zero_()
             raise RuntimeError("persistent program aborted: a device-wide barrier timed out (is another persistent "
                                "program running on this device?)")
 

@@ -49,6 +49,7 @@ class GraphSampler:
             d.eps_model.eval()
         n_steps = d.n_steps if n_steps is None else n_steps
         t0 = (d.n_steps - 1) if t_start is None else t_start
+        self.sprog = self.graph = None  # both bake in the x / t buffers allocated below: rebuilt per run
         self.x = d.rng.normal(self.shape, self.device) if x_T is None else x_T.to(self.device, torch.float32).clone()
         self.noise = torch.empty(self.shape, dtype=torch.float32, device=self.device)
         self.t32 = torch.tensor([t0], dtype=torch.int32, device=self.device)

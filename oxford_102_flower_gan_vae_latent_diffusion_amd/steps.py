@@ -94,6 +94,23 @@ class FusedAdam:
     def set_lr(self, lr):
         self.lr.fill_(lr)
 
+    def set_beta1(self, b1):
+        """torch's OneCycleLR cycles AdamW's beta1 (schedules.OneCycle). A host scalar: takes effect in eager steps and in
+        graphs captured afterwards."""
+        self.betas = (float(b1), self.betas[1])
+
+    def state_dict(self):
+        return {"m": self.m.detach().cpu(), "v": self.v.detach().cpu(), "step": self.step_count.detach().cpu(),
+                "lr": self.lr.detach().cpu(), "betas": tuple(self.betas)}
+
+    def load_state_dict(self, st):
+        self.m.copy_(st["m"])
+        self.v.copy_(st["v"])
+        self.step_count.copy_(st["step"])
+        self.lr.copy_(st["lr"])
+        if "betas" in st:
+            self.betas = tuple(st["betas"])
+
     def step(self, gscale=1.0, n=None):
         fp = self.fp
         n = fp.n_active if n is None else n
@@ -362,6 +379,10 @@ class VAEGANTrainer:
         for _ in range(2):
             self.step(data, labels, epoch=epoch, num_epochs=num_epochs)
         torch.cuda.synchronize(self.dev)
+        # the graph updates the weights it packs: every derived layout (PackCache) must be rebuilt INSIDE the graph, from
+        # the first use on - a pack made by the warm-up steps would be frozen into the replays (and freed under them)
+        self.fp.bump()
+        self.dfp.bump()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.step(self.static_data, self.static_labels, epoch=epoch, num_epochs=num_epochs)

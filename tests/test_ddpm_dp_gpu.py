@@ -1,0 +1,119 @@
+"""BASELINE config 4 on the HIP path: DDPMTrainer(process_group, world_size=2) as two ranks (gloo, both on cuda:0 - a
+one-GPU box) against the oracle's single-process step on the GLOBAL batch: averaged gradient, pre-clip norm and post-step
+weights; both ranks bit-identical. Plain eager steps AND the pipelined hipGraph path (encoder graph on stream E, denoiser
+graph + eager all-reduce + update graph on stream U)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+KEYS = ("latent_proj.weight", "layers.0.0.0.weight", "layers.2.2.weight", "attention_layers.1.in_proj_weight",
+        "attention_layers.3.out_proj.weight", "time_emb.lin1.weight", "class_emb.embedding.weight", "final.weight", "final.bias",
+        "residual_weight")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs(nb=2, B=8):
+    g = torch.Generator().manual_seed(23)
+    out = []
+    for _ in range(nb):
+        out.append(dict(data=torch.rand(B, 3, 64, 64, generator=g), labels=torch.randint(0, 102, (B,), generator=g),
+                        re=torch.randn(B, 256, generator=g), t=torch.randint(0, 1000, (B,), generator=g),
+                        eps=torch.randn(B, 256, generator=g)))
+    return out
+
+
+def _worker(rank, world, port, ret, pipelined):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import procedural_init as pinit
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M, steps
+    dev = torch.device("cuda:0")
+    ae = M.SimpleAutoencoder()
+    ae.load_state_dict(pinit.procedural_state_dict(ae.state_dict(), 42))
+    un = M.ConditionalUNet()
+    un.load_state_dict(pinit.procedural_state_dict(un.state_dict(), 44))
+    ae, un = ae.to(dev).eval(), un.to(dev).eval()  # eval: dropout off, explicit noise -> comparable with the oracle
+    tr = steps.DDPMTrainer(ae, un, lr=1e-3, process_group=dist.group.WORLD, world_size=world)
+    batches = _inputs()
+    per = batches[0]["data"].shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)
+    res = {}
+    if not pipelined:
+        for i, b in enumerate(batches):
+            tr.step(b["data"][sl].to(dev), b["labels"][sl].to(dev), b["re"][sl].to(dev), b["t"][sl].to(dev), b["eps"][sl].to(dev))
+            res["gn%d" % i] = float(tr.opt.grad_norm)
+            # the clip path scales the summed gradient by 1/world in place: the buffer now holds the global-batch gradient
+            res["g%d" % i] = {k: tr.fp.gviews[k].detach().cpu().reshape(-1)[:2048].clone() for k in KEYS}
+    else:
+        # graphs draw their own noise (Philox): seed the ranks differently, compare the ranks with each other only
+        ae.rng.manual_seed(100 + rank)
+        tr.diffusion.rng.manual_seed(200 + rank)
+        d0, l0 = batches[0]["data"][sl].to(dev), batches[0]["labels"][sl].to(dev)
+        tr.capture_pipelined(d0.clone(), l0.clone())
+        tr.prime_pipeline(d0, l0)
+        for i in range(3):
+            b = batches[(i + 1) % 2]
+            tr.replay_pipelined(b["data"][sl].to(dev), b["labels"][sl].to(dev))
+        tr.sync_pipeline()
+    torch.cuda.synchronize()
+    res["params"] = {k: un.state_dict()[k].detach().cpu().reshape(-1)[:2048].clone() for k in KEYS}
+    res["loss"] = float(tr.loss)
+    ret[rank] = res
+    dist.destroy_process_group()
+
+
+def test_dp_ddpm_step_equals_global_batch_step(dev):
+    from oracle import procedural_init as pinit, v2_oracle as O
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret, False), nprocs=world, join=True)
+    assert len(ret) == world
+    ae_sd = pinit.procedural_state_dict(M.SimpleAutoencoder().state_dict(), 42)
+    sd = pinit.procedural_state_dict(M.ConditionalUNet().state_dict(), 44)
+    opt_state = None
+
+    def close(a, b, tol, what):
+        a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+        err, scale = (a - b).abs().max().item(), max(1e-6, b.abs().max().item())
+        assert err <= tol * scale, "%s: err %.3e (ref %.3e)" % (what, err, scale)
+
+    for i, b in enumerate(_inputs()):
+        ref = O.ddpm_step(ae_sd, sd, b["data"], b["labels"], b["re"], b["t"], b["eps"], lr=1e-3, opt_state=opt_state)
+        for r in range(world):
+            close(ret[r]["gn%d" % i], ref["grad_norm"], 2e-4, "rank %d step %d grad norm" % (r, i))
+            for k in KEYS:
+                close(ret[r]["g%d" % i][k], ref["grads"][k].reshape(-1)[:2048], 5e-4, "rank %d step %d grad %s" % (r, i, k))
+        sd, opt_state = ref["new_unet_sd"], ref["opt"].state_dict()
+    for k in KEYS:
+        assert torch.equal(ret[0]["params"][k], ret[1]["params"][k]), "ranks diverged: " + k
+        a, bb = ret[0]["params"][k].double(), sd[k].reshape(-1)[:2048].double()
+        assert (a - bb).abs().max().item() <= 4.2e-3 + 1e-7, k  # two Adam steps at lr 1e-3: sign-flip bound (gradients pinned above)
+
+
+def test_dp_ddpm_pipelined_graphs_keep_ranks_identical(dev):
+    """the pipelined path (graphs on two streams around the eager all-reduce) on two ranks: finite loss, and the replicated
+    weights stay bit-identical across ranks after 3 steps although each rank drew its own noise."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret, True), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert ret[r]["loss"] == ret[r]["loss"] and ret[r]["loss"] > 0
+    assert ret[0]["loss"] != ret[1]["loss"]  # per-rank noise
+    for k in KEYS:
+        assert torch.equal(ret[0]["params"][k], ret[1]["params"][k]), "ranks diverged: " + k

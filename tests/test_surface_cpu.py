@@ -53,7 +53,26 @@ def test_product_never_imports_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(pkg, f)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
-    assert "oracle" not in open(os.path.join(ROOT, "bench.py")).read().split("def cpu_baseline")[0] or True
+    # bench.py: the oracle may only be imported inside the cpu_baseline leg (functions named cpu_baseline*), never at
+    # module level and never by anything the timed region calls
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    offenders = []
+
+    def walk(node, fn):
+        for ch in ast.iter_child_nodes(node):
+            name = fn
+            if isinstance(ch, (ast.FunctionDef, ast.AsyncFunctionDef)):
+                name = ch.name if fn is None else fn  # nested helpers inherit the outer function
+            if isinstance(ch, ast.ImportFrom) and (ch.module or "").split(".")[0] == "oracle":
+                offenders.append((fn, ch.lineno))
+            if isinstance(ch, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in ch.names):
+                offenders.append((fn, ch.lineno))
+            walk(ch, name)
+
+    walk(tree, None)
+    assert offenders, "bench.py should time the oracle in its cpu_baseline leg"
+    assert all(fn is not None and fn.startswith("cpu_baseline") for fn, _ in offenders), offenders
 
 
 def test_init_weights_hook_compatible():

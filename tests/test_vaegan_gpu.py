@@ -214,35 +214,34 @@ def test_vae_gan_step_vs_reference_loop(dev):
     ae = seeded(M.SimpleAutoencoder(), 42).to(dev).train()
     D = seeded(M.Discriminator64(), 43).to(dev).train()
     tr = steps.VAEGANTrainer(ae, D, vgg_module(dev), lr=1e-4)
-    dummy = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
-    sch = torch.optim.lr_scheduler.OneCycleLR(dummy, max_lr=1e-4, total_steps=2, pct_start=0.3, div_factor=25,
-                                              final_div_factor=1000)
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import schedules
+    sch = schedules.OneCycle(tr.opt, 1e-4, total_steps=2)  # lr AND AdamW beta1, as torch's OneCycleLR cycles them (v2:1031-1037)
     hist = {k: [] for k in ("total", "recon", "perceptual", "kl", "cls", "center", "adv")}
     for i in range(2):
-        lr = dummy.param_groups[0]["lr"]
-        out = tr.step(f["data%d" % i].to(dev), f["labels%d" % i].to(dev), epoch=0, num_epochs=1, lr=lr,
+        out = tr.step(f["data%d" % i].to(dev), f["labels%d" % i].to(dev), epoch=0, num_epochs=1,
                       reparam_eps=f["reparam_eps%d" % i].to(dev))
         for k in hist:
             hist[k].append(float(out[k]))
-        dummy.step()
         if i == 0:
             sch.step()
     for k, hk in (("total", "total"), ("recon", "recon"), ("perceptual", "perceptual"), ("kl", "kl"), ("cls", "class"),
                   ("center", "center"), ("adv", "gan")):
-        close(np.mean(hist[k]), f["hist_" + hk], 5e-4, "loss history " + hk)
+        close(np.mean(hist[k]), f["hist_" + hk], 2e-4, "loss history " + hk)
     sd = ae.state_dict()
     for k in [k for k in f if k.startswith("ae__")]:
         key = k[4:].replace("__", ".")
-        close_adam(sd[key].reshape(-1)[:64], f[k], 1e-4, "post-step AE " + key, frac=0.1)
+        close_adam(sd[key].reshape(-1)[:64], f[k], 1e-4, "post-step AE " + key, frac=0.05)
     dsd = D.state_dict()
     for k in [k for k in f if k.startswith("d__")]:
         key = k[3:].replace("__", ".")
         if "running" in key:
             close(dsd[key].reshape(-1)[:64], f[k], 1e-3, "post-step D " + key)
         else:
-            # conv biases feeding a BatchNorm have an analytically-zero gradient: Adam moves them by rounding-noise signs
-            frac = 1.0 if key in ("model.2.bias", "model.5.bias", "model.8.bias") else 0.1
-            close_adam(dsd[key].reshape(-1)[:64], f[k], 1e-4, "post-step D " + key, frac=frac)
+            # conv biases feeding a BatchNorm have an analytically-zero gradient (checked as such against the reference's
+            # gradients in test_golden_r2_gpu.py): Adam turns rounding noise into +-lr steps, nothing to compare
+            if key in ("model.2.bias", "model.5.bias", "model.8.bias"):
+                continue
+            close_adam(dsd[key].reshape(-1)[:64], f[k], 1e-4, "post-step D " + key, frac=0.05)
 
 
 def test_vae_gan_step_all_terms_vs_oracle(dev):
