@@ -3,11 +3,16 @@ step, 64x64 bs256"): frozen-encoder forward + reparameterize + q_sample + denois
 (+ one RCCL all-reduce of the flat gradient buffer per step when N > 1), v2:1254-1264.
 
     python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by the driver as torch.distributed.run (one rank per GPU, RCCL). Rank 0 prints ONE JSON line.
+N > 1 is launched by the driver as torch.distributed.run (one rank per GPU, RCCL). Rank 0 prints ONE JSON line:
+the headline metric, `roofline` (dominant kernel, timed live with HIP events), `cpu_baseline` (the CPU oracle on the
+box's host cores) and - at N = 1 - `secondary`: the other BASELINE.json configs (VAE-GAN step, 1000-step sampling +
+decode, the U-Net forward at batch 256 of the north-star target, the same headline step in native-fp32-MFMA math),
+so that this file is the single source of every number quoted in DESIGN.md.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -16,13 +21,22 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
-SPLIT_PIECE_PRODUCTS = 6        # bf16 MFMAs issued per fp32 product in the default "split" GEMM math (flowers_hip.h)
-PMC_TRAFFIC_HALO = 2.73e8         # HBM-side bytes per launch of conv3x3_halo_kernel (rocprofv3 PMC, profiles/r01_conv_kernel_pmc.md)
-# algorithmic GFLOP per image (forward MACs x2): frozen encoder fwd + denoiser fwd+bwd (3x fwd)
-GFLOP_PER_IMAGE_STEP = 2.748
-
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
+MFMA16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense 16-bit (bf16 / f16) MFMA peak (v_mfma_f32_32x32x16_*)
+BF16X3_PRODUCTS = 6             # bf16 MFMAs per fp32 product in the "split" GEMM math of gemm.hip (flowers_hip.h)
+F16X2_PRODUCTS = 3              # f16 MFMAs per fp32 product in the f16x2 conv kernels (conv_h2.hip)
+# HBM-side bytes per launch of the f16x2 conv kernels at B=256, averaged over a kernel's launches in one step: rocprofv3
+# PMC passes (FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), profiles/r02_conv_h2_pmc.md. None = not measured.
+PMC_TRAFFIC = {"h2_3x3": None, "h2_4x4": None}
+try:
+    PMC_TRAFFIC.update(json.load(open(os.path.join(ROOT, "profiles", "r02_conv_h2_pmc.json"))))
+except (OSError, ValueError):
+    pass
+# algorithmic GFLOP per image (forward MACs x 2)
+GFLOP_PER_IMAGE_STEP = 2.748     # config 3/4: frozen encoder fwd + denoiser fwd+bwd (3 x fwd)
+GFLOP_PER_IMAGE_VAEGAN = 22.75   # config 2
+GFLOP_PER_IMAGE_SAMPLE = 15.65   # config 5
+GFLOP_UNET_FWD_B256 = 4.161      # the north-star "U-Net forward at batch 256"
 
 _T0 = time.perf_counter()
 
@@ -33,8 +47,8 @@ def log(msg):
 
 
 def conv_shapes(B):
-    """The launches of the dominant kernel gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> in one step:
-    (name, B,H,W,Cin,Cout,k,stride,pad). Algorithmic FLOP per launch = 2*B*Ho*Wo*Cout*k*k*Cin."""
+    """The conv launches of the frozen encoder in one step: (name, B,H,W,Cin,Cout,k,stride,pad).
+    Algorithmic FLOP per launch = 2*B*Ho*Wo*Cout*k*k*Cin."""
     s = []
     for i, (C, H) in enumerate(((128, 32), (256, 16), (512, 8))):
         s.append(("down%d 4x4s2" % (i + 1), B, 2 * H, 2 * H, C // 2, C, 4, 2, 1))
@@ -43,15 +57,26 @@ def conv_shapes(B):
     return s
 
 
-def measure_dominant_kernel(dev, B, reps=5, halo_mode=0):
-    """HIP-event timing (on the stream the kernels are launched on = torch's current stream) of every conv launch of the
-    frozen encoder in one step, grouped by the kernel that serves it -> average duration per launch and algorithmic
-    TFLOP/s per kernel. In split mode the six 3x3 ResidualBlock convs run on conv3x3_halo_kernel (the dominant kernel
-    by time), the three 4x4 stride-2 convs on conv4x4s2_halo_kernel; in fp32 mode all nine run on gemm_kernel."""
+def _event_ms(run, reps):
+    """average duration of `run` by HIP events on torch's current stream = the stream the kernels are launched on."""
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def measure_dominant_kernel(dev, B, reps=10):
+    """HIP-event timing of every conv launch of the frozen encoder in one step, grouped by the kernel that serves it,
+    launched exactly as engine.conv_ln_infer launches it (f16x2 kernels with the fused LayerNorm2d-apply + Swish pre-op
+    where the step fuses it) -> average duration per launch and algorithmic TFLOP/s per kernel."""
     from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
     groups = {}
-    halo_on = os.environ.get("FL_CONV_HALO", "1") != "0"
-    old_mode = ops.set_conv_halo_mode(halo_mode)  # the instantiation the timed step runs (pipelined step: mode 1)
+    split = ops.get_gemm_math() == "split"
+    f16x2_on = os.environ.get("FL_CONV_F16X2", "1") != "0"
     for name, b, H, W, Ci, Co, k, s, p in conv_shapes(B):
         x = torch.empty(b, H, W, Ci, device=dev)
         ops.philox_fill(x, seed=11, mode=0)
@@ -60,43 +85,33 @@ def measure_dominant_kernel(dev, B, reps=5, halo_mode=0):
         bias = torch.zeros(Co, device=dev)
         Ho = (H + 2 * p - k) // s + 1
         y = torch.empty(b, Ho, Ho, Co, device=dev)
-        # the launch the step itself makes: in split mode the frozen encoder's weights are pre-split (B_FRAGS operand)
-        presplit = ops.get_gemm_math() == "split" and ops.presplit_ok(Ci, Co, Ho * Ho)
-        h2 = presplit and os.environ.get("FL_CONV_F16X2", "1") != "0" and ops.f16x2_ok(x, Co, k, k, s, p)
-        if h2:  # f16x2 split math (csrc/conv_h2.hip): what engine.conv_ln_infer launches for the ResidualBlock convs
+        presplit = split and ops.presplit_ok(Ci, Co, Ho * Ho)
+        h2 = presplit and f16x2_on and ops.f16x2_ok(x, Co, k, k, s, p)
+        pp = 0
+        if h2:
             wh2, geom = ops.pack_weight_f16x2(w), tuple(w.shape)
-            amax = torch.full((1,), 8.0, device=dev)  # range information: philox_fill mode 0 (normal) draws are bounded by 8
-            run = lambda: ops.conv2d_fwd_f16x2(x, wh2, geom, bias, s, p, out=y, x_amax=amax)
+            amax = torch.full((1,), 8.0, device=dev)  # range information: normal draws are bounded by 8 (swish only shrinks)
+            # every encoder conv but down2 / down3 consumes a raw conv output through the fused pre-op (engine.encoder_infer)
+            pre = None if name in ("down2 4x4s2", "down3 4x4s2") else (torch.ones(b, Ci, device=dev), torch.zeros(b, Ci, device=dev))
+            run = lambda: ops.conv2d_fwd_f16x2(x, wh2, geom, bias, s, p, out=y, x_amax=amax, pre=pre)
+            kern, pp = ("h2_3x3" if k == 3 else "h2_4x4"), F16X2_PRODUCTS
         elif presplit:
             wsp, geom = ops.split_pack_weight(w), tuple(w.shape)
             run = lambda: ops.conv2d_fwd_presplit(x, wsp, geom, bias, s, p, out=y)
+            kern, pp = ("halo_3x3" if k == 3 else "halo_4x4"), BF16X3_PRODUCTS
         else:
             run = lambda: ops.conv2d_fwd(x, w, bias, s, p, out=y)
-        kern = "gemm"
-        if h2:
-            kern = "h2"
-        elif presplit and halo_on and k == 3 and s == 1 and H in (8, 16, 32):
-            kern = "halo"
-        elif presplit and halo_on and k == 4 and s == 2 and H in (16, 32, 64):
-            kern = "halo_s2"
-        run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            run()
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+            kern, pp = "gemm", (BF16X3_PRODUCTS if split else 0)
+        ms = _event_ms(run, reps)
         fl = 2.0 * b * Ho * Ho * Co * k * k * Ci
-        by = 4.0 * b * (H * H * Ci + Ho * Ho * Co) + (6.0 if presplit else 4.0) * Co * k * k * Ci  # x + y + weights, once
-        gr_pp = 3 if h2 else (SPLIT_PIECE_PRODUCTS if ops.get_gemm_math() == "split" else 0)
-        gr = groups.setdefault(kern, dict(t=0.0, f=0.0, by=0.0, n=0, per=[], pp=gr_pp))
+        wbytes = {F16X2_PRODUCTS: 4.0, BF16X3_PRODUCTS: 6.0}.get(pp, 4.0) if presplit else 4.0
+        by = 4.0 * b * (H * H * Ci + Ho * Ho * Co) + wbytes * Co * k * k * Ci  # x + y + weights, each once
+        gr = groups.setdefault(kern, dict(t=0.0, f=0.0, by=0.0, n=0, per=[], pp=pp))
         gr["t"] += ms
         gr["f"] += fl
         gr["by"] += by
         gr["n"] += 1
         gr["per"].append((name, ms, fl / ms / 1e9))
-    ops.set_conv_halo_mode(old_mode)
     res = {}
     for kname, gr in groups.items():
         res[kname] = dict(avg_ms=gr["t"] / gr["n"], tflops=gr["f"] / gr["t"] / 1e9, flop_per_launch=gr["f"] / gr["n"],
@@ -104,43 +119,260 @@ def measure_dominant_kernel(dev, B, reps=5, halo_mode=0):
     return res
 
 
-def split_vs_fp32_mfma(dev):
-    """In-run evidence for the default GEMM math: the same convolution (res2.conv shape at batch 32, K = 2304) through
-    the exact-bf16-split path and through the native fp32 MFMA -> max |difference| relative to max |output|."""
+KERNEL_NAMES = {
+    "h2_3x3": "conv3x3_h2_kernel<W,PRE> (3x3 s1 p1 convs of the encoder's ResidualBlocks in f16x2 split math: operands scaled by a "
+              "power of two and split into 2 fp16 pieces, 3 x v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulation; input halo split "
+              "once per 16-channel chunk at LDS staging with the producer's LayerNorm2d-apply + Swish fused in, pre-split weights "
+              "through an LDS-DMA ring)",
+    "h2_4x4": "conv4x4s2_h2_kernel<Wo,PRE> (4x4 s2 p1 down-sampling convs, same math; 16-wide k group = 2 taps x 8 channels)",
+    "halo_3x3": "conv3x3_halo_kernel<W,TM> (r01 kernel, bf16x3 split math: 6 x v_mfma_f32_32x32x16_bf16 per 16 k)",
+    "halo_4x4": "conv4x4s2_halo_kernel<Wo,TM> (r01 kernel, bf16x3 split math)",
+    "gemm": "gemm_kernel<128,128,2,2,A_KC_CONV,..> (implicit-GEMM conv)",
+}
+
+
+def peak_of(pp):
+    """ceiling of the scheme a kernel issues: 16-bit dense MFMA peak / piece products per fp32 product, else the fp32 MFMA peak"""
+    return MFMA16_PEAK_TFLOPS / pp if pp else FP32_MFMA_PEAK_TFLOPS
+
+
+def f16x2_vs_fp32_mfma(dev):
+    """In-run evidence for the conv math: the same convolution (res2.conv shape at batch 32, K = 2304) through the f16x2
+    kernel and through the native fp32 MFMA -> max |difference| relative to max |output|."""
     from oxford_102_flower_gan_vae_latent_diffusion_amd import ops
     old = ops.get_gemm_math()
     x = torch.empty(32, 16, 16, 256, device=dev)
     ops.philox_fill(x, seed=21, mode=0)
     w = torch.empty(256, 3, 3, 256, device=dev)
     ops.philox_fill(w, seed=22, mode=0)
-    outs = {}
-    for mode in ("fp32", "split"):
-        ops.set_gemm_math(mode)
-        outs[mode] = ops.conv2d_fwd(x, w, None, 1, 1)
+    ops.set_gemm_math("fp32")
+    ref = ops.conv2d_fwd(x, w, None, 1, 1)
     ops.set_gemm_math(old)
-    return float((outs["split"] - outs["fp32"]).abs().max() / outs["fp32"].abs().max())
+    if not ops.f16x2_ok(x, 256, 3, 3, 1, 1):
+        return None
+    y = ops.conv2d_fwd_f16x2(x, ops.pack_weight_f16x2(w), tuple(w.shape), None, 1, 1, x_amax=torch.full((1,), 8.0, device=dev))
+    return float((y - ref).abs().max() / ref.abs().max())
 
 
-def cpu_baseline(threads, B=32, iters=6):
-    """The CPU oracle (validated restatement of the reference's step, same torch-CPU ops) timed on this box's
-    host cores on a bounded sample of the same workload. Checker code: imported only here."""
+# ------------------------------------------------------------------------------------------------ secondary configs
+def _wall(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def secondary_unet_fwd(dev):
+    """north-star target: ConditionalUNet forward at batch 256 (4.161 GFLOP of record), as one persistent program launch
+    (csrc/program.hip: v_mfma_f32_32x32x2_f32, exact fp32) and as the multi-kernel hipGraph."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import engine, modules as M, ops, program as P
+    torch.manual_seed(0)
+    un = M.ConditionalUNet().to(dev).eval()
+    B = 256
+    x = torch.empty(B, 256, device=dev)
+    ops.philox_fill(x, 1)
+    t = torch.empty(B, dtype=torch.int64, device=dev)
+    ops.philox_randint(t, 2, 1000)
+    c = torch.empty(B, dtype=torch.int64, device=dev)
+    ops.philox_randint(c, 3, 102)
+    with torch.no_grad():
+        mk = lambda: engine.unet_forward(un, x, t, c)[0]
+        mk()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = mk()
+        graph = _wall(g.replay, 200)
+        up = P.UNetProgram(un, B, dev)
+        o2 = up(x, t, c)
+        torch.cuda.synchronize()
+        up.prog.check()
+        err = float((o2 - out).abs().max())
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            up(x, t, c, out=o2)
+        pers = _wall(g2.replay, 500)
+        up.prog.check()
+    return {"workload": "ConditionalUNet forward, batch 256, eval (north-star >= 60 % of MFMA roofline target)",
+            "ms": pers * 1e3, "ms_multikernel_graph": graph * 1e3, "algorithmic_gflop": GFLOP_UNET_FWD_B256,
+            "tflops": GFLOP_UNET_FWD_B256 / pers / 1e3, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "peak_basis": "fp32 dense MFMA peak (exact-fp32 MFMA issued)",
+            "frac": GFLOP_UNET_FWD_B256 / pers / 1e3 / FP32_MFMA_PEAK_TFLOPS, "persistent_vs_multikernel_maxabs": err}
+
+
+def secondary_vaegan(dev, iters=20):
+    """BASELINE config 2: VAE-GAN full-loss step (recon + KL + VGG + PatchGAN + centre), batch 64, epoch 200, one hipGraph."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M, ops, steps
+    torch.manual_seed(0)
+    ae = M.SimpleAutoencoder().to(dev).train()
+    D = M.Discriminator64().to(dev).train()
+    vgg = M.VGGPerceptualLoss(dev)  # seeded-synthetic weights (no network for the pretrained ones)
+    tr = steps.VAEGANTrainer(ae, D, vgg, lr=1e-4)
+    B = 64
+    data = torch.empty(B, 3, 64, 64, device=dev)
+    ops.philox_fill(data, 5, mode=2)
+    labels = torch.empty(B, dtype=torch.int64, device=dev)
+    ops.philox_randint(labels, 6, 102)
+    tr.capture(data, labels, epoch=200, num_epochs=300)
+    dt = _wall(tr.replay, iters, warm=3)
+    loss = float(tr.out["total"])
+    assert loss == loss, "VAE-GAN loss is NaN"
+    tf = GFLOP_PER_IMAGE_VAEGAN * B / dt / 1e3
+    return {"workload": "BASELINE.json configs[1]: v2 VAE-GAN full loss step, 64x64 synthetic batch 64, epoch 200 (all six terms), 1 GPU",
+            "ms_per_step": dt * 1e3, "images_per_s": B / dt, "algorithmic_gflop_per_image": GFLOP_PER_IMAGE_VAEGAN, "tflops": tf,
+            "peak": peak_of(BF16X3_PRODUCTS), "peak_basis": "16-bit dense MFMA peak 2500 / 6 piece products (bf16x3 split GEMMs dominate)",
+            "frac": tf / peak_of(BF16X3_PRODUCTS), "loss": loss}
+
+
+def secondary_sample(dev):
+    """BASELINE config 5: 1000-step class-conditional sampling + VAE decode, batch 512 (one persistent launch per step)."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M
+    torch.manual_seed(0)
+    ae = M.SimpleAutoencoder().to(dev).eval()
+    un = M.ConditionalUNet().to(dev).eval()
+    d = M.ConditionalDenoiseDiffusion(un, n_steps=1000, device=dev)
+    B = 512
+    c = (torch.arange(B, device=dev) % 102).long()
+    with torch.no_grad():
+        ae.decode(d.sample((B, 256), dev, c))  # warm
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        z = d.sample((B, 256), dev, c)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        img = ae.decode(z)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    assert img.shape == (B, 3, 64, 64) and bool(torch.isfinite(img).all())
+    tot = t2 - t0
+    return {"workload": "BASELINE.json configs[4]: v2 p_sample_loop 1000 steps, class-conditional, + VAE decode, batch 512, 1 GPU",
+            "s_sampling": t1 - t0, "s_decode": t2 - t1, "images_per_s": B / tot, "ms_per_reverse_step": (t1 - t0),
+            "algorithmic_gflop_per_image": GFLOP_PER_IMAGE_SAMPLE, "tflops": GFLOP_PER_IMAGE_SAMPLE * B / tot / 1e3,
+            "peak": FP32_MFMA_PEAK_TFLOPS, "peak_basis": "fp32 dense MFMA peak (the sampler program issues exact-fp32 MFMAs)",
+            "frac": GFLOP_PER_IMAGE_SAMPLE * B / tot / 1e3 / FP32_MFMA_PEAK_TFLOPS}
+
+
+def secondary_fp32_step(dev, B, steps_n=20):
+    """the headline step again with every GEMM / conv on the native fp32 MFMA (--gemm-math fp32)."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M, ops, steps
+    old = ops.get_gemm_math()
+    ops.set_gemm_math("fp32")
+    try:
+        torch.manual_seed(1234)
+        ae = M.SimpleAutoencoder().to(dev).eval()
+        un = M.ConditionalUNet().to(dev).train()
+        tr = steps.DDPMTrainer(ae, un, lr=1e-3)
+        d = torch.empty(B, 3, 64, 64, device=dev)
+        ops.philox_fill(d, seed=2000, mode=2)
+        l = torch.empty(B, dtype=torch.int64, device=dev)
+        ops.philox_randint(l, seed=3000, hi=102)
+        tr.capture_pipelined(d.clone(), l.clone())
+        tr.prime_pipeline(d, l)
+        for _ in range(3):
+            tr.replay_pipelined(d, l)
+        tr.sync_pipeline()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps_n):
+            tr.replay_pipelined(d, l)
+        tr.sync_pipeline()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps_n
+    finally:
+        ops.set_gemm_math(old)
+    tf = GFLOP_PER_IMAGE_STEP * B / dt / 1e3
+    return {"workload": "the headline step with --gemm-math fp32 (v_mfma_f32_32x32x2_f32 everywhere)", "ms_per_step": dt * 1e3,
+            "images_per_s": B / dt, "tflops": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "peak_basis": "fp32 dense MFMA peak",
+            "frac": tf / FP32_MFMA_PEAK_TFLOPS}
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_time(fn, iters, warm):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), min(ts)
+
+
+def cpu_baseline(threads, quick=False):
+    """The CPU oracle (validated restatement of the reference's code path, same torch-CPU ops) timed on
+    this box's host cores on BOUNDED samples of configs 1, 2, 3 and 5: >= 3 warm-up and >= 10 timed iterations each, median
+    and min. Checker code: imported only here. The top-level value is config 3's (the headline workload)."""
     from oracle import procedural_init as pinit
     from oracle import v2_oracle as O
-    import json as _json
-    shapes = _json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_shapes.json")))
+    shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_shapes.json")))
     torch.set_num_threads(threads)
     ae_sd = pinit.procedural_state_dict(shapes["autoencoder"], 42)
     un_sd = pinit.procedural_state_dict(shapes["unet"], 44)
     g = torch.Generator().manual_seed(0)
+    per = {}
+    it, wm = (3, 1) if quick else (10, 3)
+    # config 3: the latent-DDPM step (frozen encoder fwd + U-Net fwd/bwd + clip + AdamW), batch 32
+    B = 32
     data, labels = torch.rand(B, 3, 64, 64, generator=g), torch.randint(0, 102, (B,), generator=g)
     re, t, eps = torch.randn(B, 256, generator=g), torch.randint(0, 1000, (B,), generator=g), torch.randn(B, 256, generator=g)
-    O.ddpm_step(ae_sd, un_sd, data, labels, re, t, eps)
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        O.ddpm_step(ae_sd, un_sd, data, labels, re, t, eps)
-    dt = time.perf_counter() - t0
-    return dict(value=B * iters / dt, unit="images/s", cores=threads, kind="port",
-                sample="%d steps of the v2 latent-DDPM step at batch %d (oracle.ddpm_step, fp32, torch %s)" % (iters, B, torch.__version__))
+    med, mn = _cpu_time(lambda: O.ddpm_step(ae_sd, un_sd, data, labels, re, t, eps), it, wm)
+    per["config3_ddpm_step"] = {"value": B / med, "unit": "images/s", "batch": B, "iters": it, "median_s": med, "min_s": mn}
+    # config 1: VAE recon-only train step (AE fwd + bwd + clip + AdamW), batch 8
+    B1 = 8
+    d1, e1 = torch.rand(B1, 3, 64, 64, generator=g), torch.randn(B1, 256, generator=g)
+
+    def c1():
+        ae = O._params(ae_sd)
+        names = [k for k, v in ae.items() if v.requires_grad]
+        opt = torch.optim.AdamW([ae[k] for k in names], lr=1e-4, weight_decay=1e-5)
+        recon = O.autoencoder_forward(ae, d1, e1)[0]
+        O.euclidean_distance_loss(recon, d1).backward()
+        torch.nn.utils.clip_grad_norm_([ae[k] for k in names if ae[k].grad is not None], 1.0)
+        opt.step()
+
+    med, mn = _cpu_time(c1, it, wm)
+    per["config1_vae_recon_step"] = {"value": B1 / med, "unit": "images/s", "batch": B1, "iters": it, "median_s": med, "min_s": mn}
+    # config 2: VAE-GAN full-loss step, batch 4, epoch 200
+    B2 = 4
+    d_sd = pinit.procedural_state_dict(shapes["discriminator"], 43)
+    vgg_sd = {"feature_extractor." + k: v for k, v in pinit.procedural_state_dict(pinit.vgg16_features16_shapes(""), 7).items()}
+    d2, l2, e2 = torch.rand(B2, 3, 64, 64, generator=g), torch.randint(0, 102, (B2,), generator=g), torch.randn(B2, 256, generator=g)
+    med, mn = _cpu_time(lambda: O.vae_gan_step(ae_sd, d_sd, vgg_sd, d2, l2, e2, epoch=200, num_epochs=300), it, wm)
+    per["config2_vaegan_step"] = {"value": B2 / med, "unit": "images/s", "batch": B2, "iters": it, "median_s": med, "min_s": mn}
+    # config 5: reverse steps at batch 512 (scaled to 1000) + decode of 64 images (scaled to 512)
+    B5 = 512
+    sched = O.schedule()
+    x5, c5, n5 = torch.randn(B5, 256, generator=g), torch.arange(B5) % 102, torch.randn(B5, 256, generator=g)
+    with torch.no_grad():
+        med_s, mn_s = _cpu_time(lambda: O.p_sample(un_sd, sched, x5, 500, c5, n5), max(it, 20), wm)
+        z64 = torch.randn(64, 256, generator=g)
+        med_d, mn_d = _cpu_time(lambda: O.decoder_forward(ae_sd, "decoder.", z64), max(3, it // 2), 1)
+    tot = 1000 * med_s + (B5 / 64) * med_d
+    per["config5_sample_decode"] = {"value": B5 / tot, "unit": "images/s", "batch": B5, "median_s_per_reverse_step": med_s,
+                                    "min_s_per_reverse_step": mn_s, "median_s_decode_64": med_d,
+                                    "extrapolated": "1000 x one reverse step + 8 x decode(64)"}
+    top = per["config3_ddpm_step"]
+    return dict(value=top["value"], unit="images/s", cores=threads, kind="port",
+                sample="%d timed + %d warm-up steps of the v2 latent-DDPM step at batch %d (oracle.ddpm_step, fp32, torch %s); median"
+                       % (it, wm, B, torch.__version__),
+                cpu_model=_cpu_model(),
+                cores_visible=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
+                cores_note="threads = min(16, visible): one GPU's share of the host, as the GPU box allots it",
+                median_s=top["median_s"], min_s=top["min_s"], per_config=per)
 
 
 def main():
@@ -152,10 +384,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="do not pipeline encoder(k+1) under the denoiser update(k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick-cpu-baseline", action="store_true", help="3 timed iterations per config instead of 10")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs (N = 1 only)")
     ap.add_argument("--gemm-math", choices=("split", "fp32"), default=None,
-                    help="split (default): fp32 operands split exactly into 3 bf16 pieces, 6 piece products on the bf16 "
-                         "matrix pipe; fp32: native v_mfma_f32_32x32x2_f32")
+                    help="split (default): f16x2 conv kernels + bf16x3 GEMMs (fp32-equivalent split math on the 16-bit matrix "
+                         "pipe); fp32: native v_mfma_f32_32x32x2_f32 everywhere")
     a = ap.parse_args()
     if os.environ.get("BENCH_WATCHDOG"):  # debugging aid: dump the python stack if a phase stalls
         import faulthandler
@@ -190,9 +424,11 @@ def main():
     if a.gemm_math is not None:
         ops.set_gemm_math(a.gemm_math)
     gemm_math = ops.get_gemm_math()
-    gemm_math_note = ("split: fp32 operands split exactly into 3 bf16 pieces (x = h+m+l), 6 of 9 piece products on "
-                      "v_mfma_f32_32x32x16_bf16, fp32 accumulation; dropped terms < 2^-21 per product "
-                      "(tests/test_kernels_gpu.py::test_split_mfma_is_fp32_equivalent); --gemm-math fp32 = native fp32 MFMA"
+    gemm_math_note = ("split: fp32-equivalent split math on the 16-bit matrix pipe. Frozen-encoder convs: f16x2 (operands scaled by a "
+                      "power of two, split by round-to-nearest into 2 fp16 pieces, 3 of 4 piece products on v_mfma_f32_32x32x16_f16, fp32 "
+                      "accumulation; measured closer to fp64 than the native fp32 MFMA, tests/test_kernels_gpu.py::"
+                      "test_f16x2_conv_is_fp32_equivalent). Other GEMMs: bf16x3 (3 round-to-nearest bf16 pieces, 6 of 9 piece products on "
+                      "v_mfma_f32_32x32x16_bf16; ::test_split_mfma_is_fp32_equivalent). --gemm-math fp32 = native fp32 MFMA"
                       if gemm_math == "split" else "fp32: native v_mfma_f32_32x32x2_f32")
 
     torch.manual_seed(1234)  # identical initial weights on every rank (random init of the v2 architecture)
@@ -292,60 +528,62 @@ def main():
     }
     if rank == 0 and world == 1:
         if not a.no_roofline:
-            pipe_mode = int(os.environ.get("FL_PIPE_HALO_MODE", "1")) if overlap else 0
-            groups = measure_dominant_kernel(dev, B, halo_mode=pipe_mode)
+            groups = measure_dominant_kernel(dev, B)
             dom = max(groups, key=lambda kname: groups[kname]["total_ms"])
             r = groups[dom]
             log("dominant kernel (%s): %.1f TFLOP/s avg over %d launches" % (dom, r["tflops"], r["launches"]))
-            split = gemm_math == "split"
-            # the fraction is taken against the peak of the instruction the kernel actually issues: in split mode one
-            # algorithmic fp32 flop costs SPLIT_PIECE_PRODUCTS bf16 flops, so the ceiling of the scheme is 2500/6 TFLOP/s
-            def peak_of(gr):  # ceiling of the scheme the kernel issues: 16-bit dense MFMA peak / piece products per fp32 product
-                return BF16_MFMA_PEAK_TFLOPS / gr["pp"] if gr["pp"] else FP32_MFMA_PEAK_TFLOPS
-            peak = peak_of(r)
-            math_note = ("6 x v_mfma_f32_32x32x16_bf16 per 16 k on exact bf16 pieces of the fp32 operands" if split
-                         else "v_mfma_f32_32x32x2_f32")
-            v3 = "1: 8 waves x 32x64 tiles, leaves VGPRs/LDS for the denoiser stream" if pipe_mode in (1, 2) else "2: 4 waves x 64x64 tiles"
-            names = {"h2": "conv3x3_h2_kernel<W> (3x3 s1 p1 conv of the encoder's ResidualBlocks in f16x2 split math: operands scaled by "
-                           "a power of two and split into 2 fp16 pieces, 3 x v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulation; halo "
-                           "split once per 16-channel chunk at LDS staging, pre-split weights via LDS-DMA ring)",
-                     "halo": "conv3x3_halo_kernel<W," + v3 + "> (3x3 s1 p1 conv of the encoder's ResidualBlocks: input halo "
-                             "staged once per 32-channel chunk, weights pre-split, " + math_note + ")",
-                     "halo_s2": "conv4x4s2_halo_kernel<Wo> (4x4 s2 p1 down-sampling convs: input halo staged once per 16-channel "
-                                "chunk, weights pre-split, " + math_note + ")",
-                     "gemm": ("gemm_kernel<128,128,2,2,A_KC_CONV,B_FRAGS> (implicit-GEMM conv, weights pre-split, " if split
-                              else "gemm_kernel<128,128,2,2,A_KC_CONV,B_KC_PLAIN> (implicit-GEMM conv, ") + math_note + ")"}
-            # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, averaged over the kernel's
-            # launches at B=256; profiles/r01_conv_kernel_pmc.md). Not re-measured live: PMC needs the profiler.
-            traffic = {"h2": None, "halo": PMC_TRAFFIC_HALO, "halo_s2": None, "gemm": 4.4e8 if split else 4.08e8}[dom] if B == 256 else None
+            peak = peak_of(r["pp"])
             out["roofline"] = {
                 "bound": "mfma",
-                "kernel": names[dom],
+                "kernel": KERNEL_NAMES[dom],
                 "achieved": r["tflops"],
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": r["tflops"] / peak,
-                "peak_basis": ("16-bit dense MFMA peak %.0f / %d piece products per fp32 product" % (BF16_MFMA_PEAK_TFLOPS, r["pp"]))
+                "peak_basis": ("16-bit dense MFMA peak %.0f / %d piece products per fp32 product" % (MFMA16_PEAK_TFLOPS, r["pp"]))
                               if r["pp"] else "fp32 dense MFMA peak",
                 "achieved_over_fp32_mfma_peak": r["tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                "split_vs_fp32_mfma_max_rel_diff": split_vs_fp32_mfma(dev),
-                "traffic": traffic,
+                "f16x2_vs_fp32_mfma_max_rel_diff": f16x2_vs_fp32_mfma(dev),
+                "traffic": PMC_TRAFFIC.get(dom) if B == 256 else None,
+                "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r02_conv_h2_pmc.md" if PMC_TRAFFIC.get(dom) else None,
                 "algorithmic_bytes_per_launch": r["bytes_per_launch"],
                 "avg_launch_ms": r["avg_ms"],
                 "algorithmic_gflop_per_launch": r["flop_per_launch"] / 1e9,
                 "launches_per_step": r["launches"],
-                "other_conv_kernels": {names[kname]: {"achieved": g2["tflops"], "frac": g2["tflops"] / peak_of(g2),
-                                                      "avg_launch_ms": g2["avg_ms"], "launches_per_step": g2["launches"]}
+                "per_launch": [{"conv": n, "ms": ms, "tflops": tf} for n, ms, tf in r["per"]],
+                "other_conv_kernels": {KERNEL_NAMES[kname]: {"achieved": g2["tflops"], "peak": peak_of(g2["pp"]),
+                                                             "frac": g2["tflops"] / peak_of(g2["pp"]), "avg_launch_ms": g2["avg_ms"],
+                                                             "launches_per_step": g2["launches"],
+                                                             "traffic": PMC_TRAFFIC.get(kname) if B == 256 else None}
                                        for kname, g2 in groups.items() if kname != dom},
                 "all_encoder_convs_tflops": sum(g2["flop_per_launch"] * g2["launches"] for g2 in groups.values())
                                             / sum(g2["total_ms"] for g2 in groups.values()) / 1e9,
+                "all_encoder_convs_ms": sum(g2["total_ms"] for g2 in groups.values()),
+                "step_tflops": GFLOP_PER_IMAGE_STEP * B * a.steps / dt / 1e3,
                 "step_frac_of_mfma_roofline": (GFLOP_PER_IMAGE_STEP * B * a.steps / dt / 1e3) / peak,
             }
+        if not a.no_secondary:
+            del tr  # free the headline trainer's graphs before the other configs build theirs
+            torch.cuda.empty_cache()
+            sec = {}
+            for name, fn in (("unet_fwd_b256", lambda: secondary_unet_fwd(dev)), ("config2_vaegan_b64", lambda: secondary_vaegan(dev)),
+                             ("config5_sample1000_decode_b512", lambda: secondary_sample(dev)),
+                             ("config3_native_fp32_mfma", lambda: secondary_fp32_step(dev, B))):
+                if gemm_math == "fp32" and name == "config3_native_fp32_mfma":
+                    continue
+                try:
+                    sec[name] = fn()
+                    log("secondary %s done" % name)
+                except Exception as e:  # a secondary leg must never cost the headline line
+                    sec[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    log("secondary %s FAILED: %s" % (name, e))
+                torch.cuda.empty_cache()
+            out["secondary"] = sec
         if not a.no_cpu_baseline:
             # one GPU's share of the host (the affinity mask of a shared 8-GPU host is much wider than this process should use)
             threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-            log("timing the CPU oracle on %d host threads ..." % threads)
-            out["cpu_baseline"] = cpu_baseline(threads)
+            log("timing the CPU oracle on %d host threads (configs 3, 1, 2, 5) ..." % threads)
+            out["cpu_baseline"] = cpu_baseline(threads, quick=a.quick_cpu_baseline)
             log("cpu baseline done")
     if rank == 0:
         print(json.dumps(out), flush=True)
