@@ -121,7 +121,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
     const int iy = oy0 - 1 + hy, ix = hx - 1;
     const bool ok = (i < ITEMS) && ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
     goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
-    sdst[j] = (i < ITEMS) ? (nl * HR + hy) * RPB + hx * PXB + c4 * 8 : -1;
+    // threads past the last item write into the 16 pad bytes of pixel 0 (branch-free staging: the conversion is interleaved
+    // with MFMAs, which needs one basic block)
+    sdst[j] = (i < ITEMS) ? (nl * HR + hy) * RPB + hx * PXB + c4 * 8 : 32;
     ssoff[j] = (nl < NI ? nl : 0) * Cin + c4 * 4;
     vmask |= (ok ? 1u : 0u) << j;
   }
@@ -155,11 +157,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
     else                                                                                                         \
       asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[NST - 1])::"memory"); \
   } while (0)
-  auto stage_store = [&](int buf, int c) {  // c: the chunk in the staging registers
-    char* dst = smem + buf * ABUF_B;
-#pragma unroll
-    for (int j = 0; j < NST; ++j) {
-      if (sdst[j] < 0) continue;
+  // one staging item: pre-op + split + two ds_write_b64 (~65 VALU instructions). Items are spread over the taps after the
+  // halo loads have landed and issued INSIDE those taps' MFMA clusters (sched_group_barrier interleave): done in one piece
+  // behind a tap's MFMAs they cost ~15 % of the kernel, with every wave converting while the matrix pipe idles
+  auto stage_item = [&](auto jc, int buf, int c) {  // c: the chunk in the staging registers
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < NST) {
+      char* dst = smem + buf * ABUF_B;
       const bool ok = (vmask >> j) & 1u;
       f32x4v v = stg[j];
       if constexpr (PRE) {
@@ -179,6 +183,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
       *reinterpret_cast<f16x4_t*>(dst + sdst[j]) = h;
       *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = l;
     }
+  };
+  auto stage_store = [&](int buf, int c) {
+    stage_item(std::integral_constant<int, 0>{}, buf, c);
+    stage_item(std::integral_constant<int, 1>{}, buf, c);
+    stage_item(std::integral_constant<int, 2>{}, buf, c);
+    stage_item(std::integral_constant<int, 3>{}, buf, c);
   };
 
   // ---- A fragment addresses (bytes inside a plane): tile row r -> halo pixel of tap (0,0); tap (dy,dx) adds dy*RPB + dx*PXB
@@ -230,14 +240,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  auto mfma12 = [&](const Frags& f) {
-    __builtin_amdgcn_s_setprio(1);
+  // PRIO: s_setprio(1) / (0) around the cluster keep hipcc from moving MFMAs across the barriers (guide T5); the taps that
+  // interleave staging VALU work with their MFMAs must not have them (s_setprio fences the scheduler)
+  auto mfma12 = [&](const Frags& f, auto prio) {
+    constexpr bool PRIO = decltype(prio)::value;
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #define FL_PIECE(pa, pb)                                                                         \
     _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) \
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm][pa], f.b[tn][pb], acc[tm][tn], 0, 0, 0);
     FL_PIECE(1, 0) FL_PIECE(0, 1) FL_PIECE(0, 0)  // l*h, h*l, h*h: smallest terms first
 #undef FL_PIECE
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- prologue: chunk 0 staged, taps 0..2 of chunk 0 in the ring, fragments of tap 0 in registers
@@ -266,7 +279,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
     if constexpr (T == 0) stage_load(c + 1 < nC ? c + 1 : c);
     frag_load(nxt, (c + C1) & 1, (T1 / 3) * RPB + (T1 % 3) * PXB, T1 % 3);
     __builtin_amdgcn_sched_barrier(0);
-    mfma12(cur);
+    if constexpr (T >= 3 && T < 3 + NST) {  // staging item T - 3 of the NEXT chunk, interleaved with this tap's MFMAs
+      stage_item(std::integral_constant<int, T - 3>{}, (c + 1) & 1, c + 1 < nC ? c + 1 : c);
+      mfma12(cur, std::false_type{});
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+      }
+    } else {
+      mfma12(cur, std::true_type{});
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (T == 0 || T == 1) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST + 1) : "memory");
@@ -275,7 +298,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
     } else {
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     }
-    if constexpr (T == 3) stage_store((c + 1) & 1, c + 1 < nC ? c + 1 : c);  // the other buffer: last read while tap 7 of the previous chunk ran
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) as a builtin: hipcc then knows the fragment reads have landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
