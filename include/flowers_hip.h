@@ -224,6 +224,14 @@ int fl_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
                      const float* mean, const float* rstd, const float* R, float* dx, float* dw, float* db, int rows, int D,
                      int act, float act_param, void* ws, size_t ws_bytes, fl_stream_t stream);
 
+/* Fused multi-head self-attention over the HW tokens of a feature map (UNetAttentionBlock, v2:446-457): one launch for
+ * softmax(scale * Q K^T) V of every (image, head), no (HW x HW) tensor in HBM. qkv (B,HW,3C): channel = which*C + head*d + i
+ * (NHWC output of the 1x1 qkv conv); out (B,HW,C): channel = i*heads + head (the d-major merge of v2:456-457); P optional
+ * (B,heads,HW,HW): the normalised weights, kept only when a backward will need them. QK^T and PV on v_mfma_f32_32x32x2_f32
+ * (exact fp32); the score tile is built transposed so that the row softmax is in-lane arithmetic + one wave shuffle and the
+ * accumulator tile feeds the PV MFMA as it stands. Needs HW % 32 == 0, C / heads <= 32. */
+int fl_attention_fwd(const float* qkv, float* out, float* P, int B, int HW, int C, int heads, float scale, fl_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * Residual-block tail: CALayer (v2:53-67) x SpatialAttention (v2:69-81) x residual+Swish
  * (v2:176-177) fused into two streaming passes.  u = s[b,c]*(y*scale[b,c]+shift[b,c]).

@@ -511,6 +511,21 @@ def res_tail_out(y, scale=None, shift=None, s=None, map_=None, saw=None, xres=No
     return (out, att) if save_att else out
 
 
+def attention_fwd(qkv, heads, scale, want_p=False):
+    """qkv (B,H,W,3C) -> merged (B,H,W,C) [channel = i*heads + head], optionally P (B,heads,HW,HW). See fl_attention_fwd."""
+    _chk(qkv)
+    B, H, W, C3 = qkv.shape
+    C, HW = C3 // 3, H * W
+    out = new((B, H, W, C), qkv)
+    P = new((B, heads, HW, HW), qkv) if want_p else None
+    _lib.call("fl_attention_fwd", _p(qkv), _p(out), _p(P), B, HW, C, int(heads), float(scale), _stream())
+    return (out, P) if want_p else out
+
+
+def attention_ok(HW, C, heads):
+    return HW % 32 == 0 and C % heads == 0 and C // heads <= 32
+
+
 # --------------------------------------------------------------------------- elementwise & co
 def nchw_to_nhwc(x, Cpad=None):
     _chk(x)

@@ -91,3 +91,57 @@ def renoise(diffusion, x0, t, eps=None):
     """x_t ~ q(x_t | x_0) for an integer t shared by the batch (v2:928-935 uses alpha_bar[t] directly)."""
     tt = torch.full((x0.shape[0],), int(t), dtype=torch.int64, device=x0.device)
     return diffusion.q_sample(x0, tt, eps)
+
+
+@torch.no_grad()
+def denoise_from_many(diffusion, x_T, t_starts, c=None, use_graph=True, persistent=None):
+    """visualize_denoising_steps (v2:687-691) as ONE batched run: the reference restarts from the same x_T for each t in
+    `t_starts` and walks t..0 one p_sample at a time (sum(t+1) sequential steps). Here the restarts are the row groups of one
+    batch (group i = the x_T rows started at the i-th largest t): at global step s exactly the groups with t >= s are alive,
+    so the run is len(t_starts) phases of (t_i - t_{i+1}) steps on a growing row prefix - max(t)+1 sequential steps in all.
+    Returns (len(t_starts) * n, latent) in the ORDER of `t_starts` (fresh, independent noise per trajectory, like the
+    reference's per-call randn_like)."""
+    n = x_T.shape[0]
+    order = sorted(range(len(t_starts)), key=lambda i: -int(t_starts[i]))
+    ts = [int(t_starts[i]) for i in order]
+    G = len(ts)
+    x = x_T.to(torch.float32).repeat(G, 1).contiguous()
+    cc = c.long().repeat(G).contiguous() if c is not None else None
+    for i, t in enumerate(ts):
+        rows = (i + 1) * n
+        nxt = ts[i + 1] if i + 1 < G else -1
+        if t - nxt <= 0:
+            continue
+        g = GraphSampler(diffusion, (rows, x.shape[1]), x.device, cc[:rows] if cc is not None else None, use_graph=use_graph,
+                         persistent=persistent)
+        x[:rows].copy_(g.run(x_T=x[:rows], n_steps=t - nxt, t_start=t))
+    out = torch.empty_like(x)
+    for pos, i in enumerate(order):  # back to the caller's order
+        out[i * n:(i + 1) * n].copy_(x[pos * n:(pos + 1) * n])
+    return out
+
+
+@torch.no_grad()
+def denoising_steps_decoded(diffusion, autoencoder, x_T, t_starts, c=None):
+    """v2:687-693: the partial trajectories above, decoded in one decoder batch -> (len(t_starts), n, 3, 64, 64)."""
+    z = denoise_from_many(diffusion, x_T, t_starts, c)
+    img = autoencoder.decode(z)
+    return img.view(len(t_starts), x_T.shape[0], *img.shape[1:]), z
+
+
+@torch.no_grad()
+def renoise_decode(diffusion, autoencoder, x0, t_list, eps):
+    """create_diffusion_animation's frames (v2:928-935) as two batched ops: every frame re-noises the SAME clean latent with
+    the SAME eps (the reference re-seeds before each randn_like) at its own t - one fused q_sample over (frames x n) rows with
+    per-row t (t = 0 keeps x0 untouched, v2:930) - and all frames go through the decoder together.
+    Returns (len(t_list), n, 3, 64, 64)."""
+    n, F = x0.shape[0], len(t_list)
+    x0r = x0.to(torch.float32).repeat(F, 1).contiguous()
+    er = eps.to(torch.float32).repeat(F, 1).contiguous()
+    tt = torch.tensor([int(t) for t in t_list for _ in range(n)], dtype=torch.int64, device=x0.device)
+    xt = diffusion.q_sample(x0r, tt, er)
+    for f, t in enumerate(t_list):
+        if int(t) <= 0:
+            xt[f * n:(f + 1) * n].copy_(x0r[f * n:(f + 1) * n])
+    img = autoencoder.decode(xt)
+    return img.view(F, n, *img.shape[1:]), xt

@@ -63,19 +63,24 @@ class UNetAttentionBlock(nn.Module):
         xn = ops.affine_act(xh, sc, sh)
         # 1x1 conv = GEMM over pixels; channel j of qkv = which*C + head*d + i  (reshape(b,3,heads,d,hw), v2:447)
         qkv = ops.conv2d_fwd(xn, self._pk.conv(self.qkv), self.qkv.bias.detach(), 1, 0)  # (B,H,W,3C)
-        o = torch.empty(B, nh, HW, d, dtype=torch.float32, device=xh.device)
         scale = float(d) ** -0.5
-        for b in range(B):
-            base = b * HW * 3 * C
-            for h in range(nh):
-                q = _flat_from(qkv, base + h * d)
-                k = _flat_from(qkv, base + C + h * d)
-                v = _flat_from(qkv, base + 2 * C + h * d)
-                s = ops.gemm(q, k, HW, HW, d, lda=3 * C, ldb=3 * C)                    # S = Q K^T   (HW x HW)
-                p = ops.softmax_rows(s, scale)                                        # softmax(scale * S)
-                ops.gemm(p, v, HW, d, HW, a_layout=ops.KC, b_layout=ops.KS, lda=HW, ldb=3 * C, out=o[b, h])  # P V
-        # out.permute(0,3,1,2).reshape(b,c,h,w) (v2:456-457): channel = i*heads + head  ((B,heads,HW,d)->(B,HW,d,heads))
-        merged = ops.pack_conv_weight(o).view(B, H, W, C)
+        if ops.attention_ok(HW, C, nh):
+            # one fused launch: QK^T, row softmax and PV for every (image, head); the merged tensor comes out in the d-major
+            # channel order of v2:456-457
+            merged = ops.attention_fwd(qkv, nh, scale)
+        else:
+            o = torch.empty(B, nh, HW, d, dtype=torch.float32, device=xh.device)
+            for b in range(B):
+                base = b * HW * 3 * C
+                for h in range(nh):
+                    q = _flat_from(qkv, base + h * d)
+                    k = _flat_from(qkv, base + C + h * d)
+                    v = _flat_from(qkv, base + 2 * C + h * d)
+                    s = ops.gemm(q, k, HW, HW, d, lda=3 * C, ldb=3 * C)                    # S = Q K^T   (HW x HW)
+                    p = ops.softmax_rows(s, scale)                                        # softmax(scale * S)
+                    ops.gemm(p, v, HW, d, HW, a_layout=ops.KC, b_layout=ops.KS, lda=HW, ldb=3 * C, out=o[b, h])  # P V
+            # out.permute(0,3,1,2).reshape(b,c,h,w) (v2:456-457): channel = i*heads + head  ((B,heads,HW,d)->(B,HW,d,heads))
+            merged = ops.pack_conv_weight(o).view(B, H, W, C)
         return ops.conv2d_fwd(merged, self._pk.conv(self.proj), self.proj.bias.detach(), 1, 0, R=xh)
 
     # ---- training path -------------------------------------------------------------------------------------------
@@ -88,19 +93,22 @@ class UNetAttentionBlock(nn.Module):
         gn = ops.groupnorm_stats(xh, nw, nb, 1, self.norm.eps)
         xn = ops.affine_act(xh, gn[0], gn[1])
         qkv = ops.conv2d_fwd(xn, self._pk.conv(self.qkv), self.qkv.bias.detach(), 1, 0)
-        o = torch.empty(B, nh, HW, d, dtype=torch.float32, device=xh.device)
-        P = torch.empty(B, nh, HW, HW, dtype=torch.float32, device=xh.device)
         scale = float(d) ** -0.5
-        for b in range(B):
-            base = b * HW * 3 * C
-            for h in range(nh):
-                q = _flat_from(qkv, base + h * d)
-                k = _flat_from(qkv, base + C + h * d)
-                v = _flat_from(qkv, base + 2 * C + h * d)
-                s_ = ops.gemm(q, k, HW, HW, d, lda=3 * C, ldb=3 * C)
-                P[b, h] = ops.softmax_rows(s_, scale)
-                ops.gemm(P[b, h], v, HW, d, HW, a_layout=ops.KC, b_layout=ops.KS, lda=HW, ldb=3 * C, out=o[b, h])
-        merged = ops.pack_conv_weight(o).view(B, H, W, C)
+        if ops.attention_ok(HW, C, nh):
+            merged, P = ops.attention_fwd(qkv, nh, scale, want_p=True)  # fused forward; P kept for the backward
+        else:
+            o = torch.empty(B, nh, HW, d, dtype=torch.float32, device=xh.device)
+            P = torch.empty(B, nh, HW, HW, dtype=torch.float32, device=xh.device)
+            for b in range(B):
+                base = b * HW * 3 * C
+                for h in range(nh):
+                    q = _flat_from(qkv, base + h * d)
+                    k = _flat_from(qkv, base + C + h * d)
+                    v = _flat_from(qkv, base + 2 * C + h * d)
+                    s_ = ops.gemm(q, k, HW, HW, d, lda=3 * C, ldb=3 * C)
+                    P[b, h] = ops.softmax_rows(s_, scale)
+                    ops.gemm(P[b, h], v, HW, d, HW, a_layout=ops.KC, b_layout=ops.KS, lda=HW, ldb=3 * C, out=o[b, h])
+            merged = ops.pack_conv_weight(o).view(B, H, W, C)
         out = ops.conv2d_fwd(merged, self._pk.conv(self.proj), self.proj.bias.detach(), 1, 0, R=xh)
         return ops.nhwc_to_nchw(out), (xh, gn, xn, qkv, P, merged)
 

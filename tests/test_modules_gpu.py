@@ -394,6 +394,48 @@ def test_sampler_helpers(dev, unet):
     close(xt, torch.sqrt(ab) * a + torch.sqrt(1 - ab) * eps, 1e-6, "renoise")
 
 
+def test_batched_partial_trajectories(dev, ae, unet):
+    """f4: visualize_denoising_steps' restarts (v2:687-691) as one batched run. With the noise switched off (a zero-noise
+    rng) the batched groups must reproduce the separate t..0 walks; with noise on, the t = 0 group is one deterministic
+    step and the result keeps the caller's order. create_diffusion_animation's frames (v2:928-935): same eps for every t,
+    t = 0 keeps the clean latent, one decoder batch."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import sampler
+    d = M.ConditionalDenoiseDiffusion(unet, n_steps=1000, device=dev)
+    n = 3
+    c = torch.tensor([4, 50, 101], device=dev)
+    x_T = torch.randn(n, 256, generator=torch.Generator().manual_seed(8)).to(dev)
+    ts = [0, 30, 12, 5]
+
+    class ZeroNoise:
+        def normal(self, shape, device, out=None):
+            return out.zero_() if out is not None else torch.zeros(tuple(shape), device=device)
+
+    real_rng, d.rng = d.rng, ZeroNoise()
+    try:
+        many = sampler.denoise_from_many(d, x_T, ts, c, persistent=False)
+        for gi, t in enumerate(ts):
+            sep = sampler.GraphSampler(d, (n, 256), dev, c, persistent=False).run(x_T=x_T, n_steps=t + 1, t_start=t)
+            close(many[gi * n:(gi + 1) * n], sep, 2e-5, "group t=%d == its own t..0 walk" % t)
+    finally:
+        d.rng = real_rng
+    # default (persistent program, inline Philox noise): the t = 0 group takes one noise-free step (v2:588)
+    many = sampler.denoise_from_many(d, x_T, ts, c)
+    close(many[0:n], d.p_sample(x_T, 0, c), 2e-5, "t = 0 group")
+    assert many.shape == (len(ts) * n, 256) and bool(torch.isfinite(many).all())
+    imgs, z = sampler.denoising_steps_decoded(d, ae, x_T, [3, 0], c)
+    assert imgs.shape == (2, n, 3, 64, 64) and bool(torch.isfinite(imgs).all())
+    close(imgs[1], ae.decode(z[n:2 * n]), 1e-5, "decoded together == decoded alone")
+    # animation frames
+    clean = z[n:2 * n]
+    eps = torch.randn(n, 256, generator=torch.Generator().manual_seed(9)).to(dev)
+    frames, xt = sampler.renoise_decode(d, ae, clean, [0, 400, 999], eps)
+    assert frames.shape == (3, n, 3, 64, 64)
+    assert torch.equal(xt[0:n], clean.float())
+    ab = d.alpha_bar[400]
+    close(xt[n:2 * n], torch.sqrt(ab) * clean + torch.sqrt(1 - ab) * eps, 1e-6, "frame t=400")
+    close(frames[2], ae.decode(xt[2 * n:3 * n]), 1e-5, "frame decode")
+
+
 @pytest.mark.parametrize("B", [1, 3])
 def test_edge_batch_sizes_vs_oracle(dev, ae, unet, B):
     """ragged / minimal batches: tile masks, split-K and the fused-statistics epilogue must not depend on B."""

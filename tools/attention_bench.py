@@ -1,0 +1,31 @@
+"""A18 attention block timing: fused attention kernel (fl_attention_fwd) vs the per-(image, head) GEMM + softmax loops it
+replaces, at (B, C, H) = (256, 128, 16) [4 heads, d = 32, 256 tokens]. Usage: python tools/attention_bench.py"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oxford_102_flower_gan_vae_latent_diffusion_amd import ops, unet_blocks
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+B, C, H, nh = 256, 128, 16, 4
+blk = unet_blocks.UNetAttentionBlock(C, nh).to(dev).eval()
+x = torch.empty(B, H, H, C, device=dev); ops.philox_fill(x, 3)
+def t(fn, n):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+with torch.no_grad():
+    y1 = blk.forward_nhwc(x)
+    qkv = torch.empty(B, H, H, 3 * C, device=dev); ops.philox_fill(qkv, 4)
+    core = t(lambda: ops.attention_fwd(qkv, nh, 32 ** -0.5), 20)
+    full = t(lambda: blk.forward_nhwc(x), 20)
+    ok = ops.attention_ok
+    ops.attention_ok = lambda *a: False
+    xs = x[:8].contiguous()
+    y0 = blk.forward_nhwc(xs)
+    loop8 = t(lambda: blk.forward_nhwc(xs), 3)
+    ops.attention_ok = ok
+    err = float((y1[:8] - y0).abs().max() / y0.abs().max())
+fl = 4.0 * B * nh * (H * H) ** 2 * (C // nh)  # QK^T + PV
+print("fused attention core (B=%d, %d heads, d=%d, %d tokens): %.3f ms = %.1f TFLOP/s (exact fp32 MFMA); whole block %.3f ms; "
+      "loop path at B=8: %.2f ms (x32 = %.0f ms at B=256); fused vs loops max rel diff %.2e" %
+      (B, nh, C // nh, H * H, core, fl / core / 1e9, full, loop8, loop8 * 32, err))
