@@ -426,7 +426,7 @@ def main():
     gemm_math = ops.get_gemm_math()
     gemm_math_note = ("split: fp32-equivalent split math on the 16-bit matrix pipe. Frozen-encoder convs: f16x2 (operands scaled by a "
                       "power of two, split by round-to-nearest into 2 fp16 pieces, 3 of 4 piece products on v_mfma_f32_32x32x16_f16, fp32 "
-                      "accumulation; measured closer to fp64 than the native fp32 MFMA, tests/test_kernels_gpu.py::"
+                      "accumulation; error vs fp64 <= 3e-6 of the output max, 2-4x the native fp32 MFMA kernel's, tests/test_kernels_gpu.py::"
                       "test_f16x2_conv_is_fp32_equivalent). Other GEMMs: bf16x3 (3 round-to-nearest bf16 pieces, 6 of 9 piece products on "
                       "v_mfma_f32_32x32x16_bf16; ::test_split_mfma_is_fp32_equivalent). --gemm-math fp32 = native fp32 MFMA"
                       if gemm_math == "split" else "fp32: native v_mfma_f32_32x32x2_f32")

@@ -119,8 +119,8 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
 /* 3x3 / stride 1 / pad 1 and 4x4 / stride 2 / pad 1 forward conv in "f16x2" split math (csrc/conv_h2.hip; the
  * ResidualBlock and down-sampling convs of the frozen encoder, v2:159-178, v2:191-213). Every fp32 operand is scaled by a power of two and split by round-to-nearest into two fp16
  * pieces x*2^e = h + l (+ <= 2^-22 |x| 2^e); a product is 3 of the 4 piece products on v_mfma_f32_32x32x16_f16 (piece
- * products exact, fp32 accumulation): fp32-equivalent accuracy (measured better than the native fp32 MFMA) at half
- * the matrix instructions of the bf16x3 scheme. fl_pack_weight_f16x2 scales (per tensor, amax -> [2^14,2^15)), splits
+ * products exact, fp32 accumulation): error vs fp64 0.5-1.7e-6 of the output's max for K = 1024..4608 (2-4x the native fp32
+ * MFMA kernel's accumulation error, the class of the bf16x3 scheme) at half the matrix instructions of the bf16x3 scheme. fl_pack_weight_f16x2 scales (per tensor, amax -> [2^14,2^15)), splits
  * and lays out the packed weight [Cout][kh*kw*Cin] once (fl_pack_weight_f16x2_bytes(N,K) = 256 + 4*N*K bytes;
  * layout 0 for the 3x3 kernel, 1 for the 4x4 one, whose 16-wide k groups pair two taps x 8 channels).
  * Activations are scaled by 2^x_exp, or - when x_amax != NULL - by the power of two that maps *x_amax (a device float

@@ -5,8 +5,9 @@
 //   X = x * 2^e,  h = f16(X),  l = f16(X - h)        (X - h is exact in fp32; |X - h - l| <= 2^-22 |X|, unbiased)
 // and a product is assembled from 3 of the 4 piece products (l*h, h*l, h*h - smallest first) on
 // v_mfma_f32_32x32x16_f16: an f16 x f16 product is exact in fp32, accumulation is the fp32 accumulation of the MFMA. The
-// dropped l*l term is <= 2^-22 |xy|. Measured against fp64 this is MORE accurate than the native fp32 MFMA and than the
-// 6-product bf16x3 scheme of gemm.hip (tests/test_kernels_gpu.py::test_f16x2_conv_is_fp32_equivalent), at 3 matrix
+// dropped l*l term is <= 2^-22 |xy|. Measured against fp64: 0.5-1.7e-6 of the output's max for K = 1024..4608, i.e. 2-4x the
+// native fp32 MFMA kernel's own accumulation error and the same class as the 6-product bf16x3 scheme of gemm.hip
+// (tests/test_kernels_gpu.py::test_f16x2_conv_is_fp32_equivalent, profiles/r02_conv_h2_nine_shapes.txt), at 3 matrix
 // instructions per 16 k-values instead of 6. The power-of-two scales keep every piece inside fp16's exponent range:
 // weights are scaled per tensor at pack time (amax -> [2^14, 2^15), fl_pack_weight_f16x2), activations by 2^a_exp or
 // from a device-resident amax word kept by the producing kernel; values > 2^-17 amax keep both pieces in the normal

@@ -589,3 +589,132 @@ def test_conv_fwd_presplit_weight(dev, B, Cin, Cout, HW, k, s, p, halo_mode):
     close(sc, sc3.cpu(), tol=1e-5)
     close(sh, sh3.cpu(), tol=1e-5)
     close(mean, ref.mean((2, 3)), tol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------- f16x2 conv kernels (conv_h2.hip)
+H2_CASES = [  # B, Cin, Cout, H, k, s, p: every width of both kernels; several N tiles; tiles below an image's first row; 4 images per tile
+    (2, 128, 128, 32, 3, 1, 1), (1, 256, 256, 16, 3, 1, 1), (4, 512, 512, 8, 3, 1, 1), (1, 128, 256, 32, 3, 1, 1), (8, 64, 128, 8, 3, 1, 1),
+    (1, 64, 128, 64, 4, 2, 1), (1, 128, 256, 32, 4, 2, 1), (4, 256, 512, 16, 4, 2, 1), (2, 8, 128, 32, 4, 2, 1), (3, 32, 128, 32, 3, 1, 1),
+]
+
+
+def _h2_setup(B, Cin, Cout, H, k, s, p, seed=0):
+    x = rnd(B, Cin, H, H, seed=seed + 1)
+    x = x * torch.sigmoid(x)
+    w = rnd(Cout, Cin, k, k, seed=seed + 2, scale=(2.0 / (k * k * Cin)) ** 0.5)
+    b = rnd(Cout, seed=seed + 3, scale=0.1)
+    return x, w, b
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,k,s,p", H2_CASES)
+def test_f16x2_conv_is_fp32_equivalent(dev, B, Cin, Cout, H, k, s, p):
+    """conv_h2.hip: operands scaled by powers of two and split (round to nearest) into two fp16 pieces, 3 of 4 piece products
+    on v_mfma_f32_32x32x16_f16. Each operand carries a 2^-22 relative representation error (unbiased), so against the exact
+    (fp64) convolution the kernel sits at 2-4x the native fp32 MFMA kernel's own accumulation error: <= 3e-6 of the output's
+    max for K up to 4608, the same class as the bf16x3 math (measured side by side in tools/conv_h2_bench.py) and 30x inside
+    the 1e-4 parity tolerance. Checked with a static activation exponent, with an amax bound, with tiny activations (low pieces in fp16's
+    subnormal range) and with the fused LayerNorm2d statistics / bias / activation epilogue."""
+    x, w, b = _h2_setup(B, Cin, Cout, H, k, s, p)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p)
+    xh, wp, bd = nhwc(x).to(dev), ops.pack_conv_weight(w.to(dev)), b.to(dev)
+    assert ops.f16x2_ok(xh, Cout, k, k, s, p)
+    geom = tuple(wp.shape)
+    wh2 = ops.pack_weight_f16x2(wp)
+    old = ops.get_gemm_math()
+    ops.set_gemm_math("fp32")
+    y32 = nchw(ops.conv2d_fwd(xh, wp, bd, s, p)).cpu().double()
+    ops.set_gemm_math(old)
+    e32 = ((y32 - ref).abs().max() / ref.abs().max()).item()
+    amax = torch.full((1,), float(x.abs().max()) * 1.5, device=dev)
+    for kw in (dict(), dict(x_amax=amax)):
+        y = nchw(ops.conv2d_fwd_f16x2(xh, wh2, geom, bd, s, p, **kw)).cpu().double()
+        e = ((y - ref).abs().max() / ref.abs().max()).item()
+        assert e <= 3e-6 and e <= max(6.0 * e32, 1e-6), "f16x2 %.3e vs fp32 MFMA %.3e %s" % (e, e32, kw.keys())
+    # tiny activations under the static exponent
+    ys = nchw(ops.conv2d_fwd_f16x2(xh * 1e-3, wh2, geom, None, s, p)).cpu().double()
+    refs = (ref - b.double().view(1, -1, 1, 1)) * 1e-3
+    assert ((ys - refs).abs().max() / refs.abs().max()).item() <= 4e-6
+    # activation epilogue + fused LayerNorm2d statistics
+    yr = nchw(ops.conv2d_fwd_f16x2(xh, wh2, geom, bd, s, p, act=ops.ACT_RELU, x_amax=amax)).cpu().double()
+    close(yr, ref.clamp_min(0), tol=4e-6)
+    Ho = ref.shape[-1]
+    if (Ho * Ho) % 64 == 0:
+        lnw, lnb = rnd(Cout, seed=9).abs() + 0.5, rnd(Cout, seed=10)
+        _, (sc, sh, mean, rstd) = ops.conv2d_fwd_f16x2(xh, wh2, geom, bd, s, p, ln_w=lnw.to(dev), ln_b=lnb.to(dev), x_amax=amax)
+        m = ref.mean(dim=(2, 3))
+        r = 1.0 / torch.sqrt(ref.var(dim=(2, 3), unbiased=False) + 1e-5)
+        close(mean, m, tol=2e-5)
+        close(rstd, r, tol=2e-5)
+        close(sc, r * lnw.double(), tol=2e-5)
+        close(sh, lnb.double() - m * r * lnw.double(), tol=5e-5)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,k,s,p", [H2_CASES[0], H2_CASES[2], H2_CASES[5], H2_CASES[7]])
+def test_f16x2_conv_fused_preop(dev, B, Cin, Cout, H, k, s, p):
+    """pre-op: the conv consumes swish(x * scale[b,c] + shift[b,c]) (the producer's LayerNorm2d-apply + Swish) inside its halo
+    staging; zero padding applies to the TRANSFORMED tensor. Against fl_affine_act + the same conv, and against fp64."""
+    x, w, b = _h2_setup(B, Cin, Cout, H, k, s, p, seed=20)
+    sc, sh = rnd(B, Cin, seed=31).abs() + 0.5, rnd(B, Cin, seed=32, scale=0.5)
+    a = x.double() * sc.double().view(B, Cin, 1, 1) + sh.double().view(B, Cin, 1, 1)
+    a = a * torch.sigmoid(a)
+    ref = F.conv2d(a, w.double(), b.double(), stride=s, padding=p)
+    xh, wp, bd = nhwc(x).to(dev), ops.pack_conv_weight(w.to(dev)), b.to(dev)
+    wh2, geom = ops.pack_weight_f16x2(wp), tuple(wp.shape)
+    bound = torch.full((1,), float(a.abs().max()) * 1.5, device=dev)
+    y = nchw(ops.conv2d_fwd_f16x2(xh, wh2, geom, bd, s, p, x_amax=bound, pre=(sc.to(dev), sh.to(dev))))
+    close(y, ref, tol=3e-6)
+    xa = ops.affine_act(xh, sc.to(dev), sh.to(dev), act=ops.ACT_SWISH)
+    y2 = nchw(ops.conv2d_fwd_f16x2(xa, wh2, geom, bd, s, p, x_amax=bound))
+    close(y, y2.cpu(), tol=3e-6)
+
+
+def test_f16x2_range_is_loud_not_silent(dev):
+    """|x| * 2^e beyond fp16's range must poison the output (inf - inf = NaN), never pass silently; a correct amax bound
+    makes the same data exact again."""
+    x, w, b = _h2_setup(1, 128, 128, 32, 3, 1, 1, seed=40)
+    x = x * 5000.0  # static exponent 6: |x| * 64 overflows fp16
+    xh, wp = nhwc(x).to(dev), ops.pack_conv_weight(w.to(dev))
+    wh2, geom = ops.pack_weight_f16x2(wp), tuple(wp.shape)
+    y = ops.conv2d_fwd_f16x2(xh, wh2, geom, None, 1, 1)
+    assert not bool(torch.isfinite(y).all())
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    y = nchw(ops.conv2d_fwd_f16x2(xh, wh2, geom, None, 1, 1, x_amax=torch.full((1,), float(x.abs().max()), device=dev)))
+    close(y, ref, tol=2e-6)
+
+
+def test_f16x2_rejects_unsupported_shapes(dev):
+    x = torch.zeros(1, 24, 24, 128, device=dev)
+    assert not ops.f16x2_ok(x, 128, 3, 3, 1, 1)
+    wh2 = ops.pack_weight_f16x2(torch.zeros(128, 3, 3, 128, device=dev))
+    with pytest.raises(RuntimeError, match="unsupported shape"):
+        ops.conv2d_fwd_f16x2(x, wh2, (128, 3, 3, 128), None, 1, 1)
+    with pytest.raises(RuntimeError, match="pre_scale"):
+        from oxford_102_flower_gan_vae_latent_diffusion_amd import lib as _l
+        xx = torch.zeros(1, 32, 32, 128, device=dev)
+        yy = torch.zeros(1, 32, 32, 128, device=dev)
+        import ctypes
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        _l.call("fl_conv2d_fwd_f16x2", P(xx), P(wh2), None, P(yy), 1, 32, 32, 128, 128, 3, 3, 1, 1, 0, 0.0, None, None, 1e-5, None, None,
+                None, None, None, 6, P(xx), None, None, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
+def test_encoder_infer_f16x2_fused_vs_oracle(dev):
+    """the frozen encoder at a batch where every conv runs on the f16x2 kernels with the fused pre-op (B*8*8 % 256 == 0),
+    against the CPU oracle, with and without materialised skip features."""
+    from oracle import procedural_init as pinit, v2_oracle as O
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import engine, modules as M
+    ae = M.SimpleAutoencoder()
+    ae.load_state_dict(pinit.procedural_state_dict(ae.state_dict(), 42))
+    sd = {k: v.clone() for k, v in ae.state_dict().items()}
+    ae = ae.to(dev).eval()
+    B = 8
+    data = torch.rand(B, 3, 64, 64, generator=torch.Generator().manual_seed(77))
+    with torch.no_grad():
+        mu_r, lv_r, feats_r = O.encoder_forward(sd, "encoder.", data, return_features=True)
+        mu, lv, feats = engine.encoder_infer(ae.encoder, data.to(dev), want_feats=True)
+        mu2, lv2, feats2 = engine.encoder_infer(ae.encoder, data.to(dev), want_feats=False)
+    close(mu, mu_r, tol=1e-4)
+    close(lv, lv_r, tol=1e-4)
+    assert torch.equal(mu, mu2) and torch.equal(lv, lv2) and feats2[0] is None
+    for f, fr in zip(feats, feats_r):
+        close(f.permute(0, 3, 1, 2), fr, tol=1e-4)
