@@ -64,9 +64,9 @@ __device__ __forceinline__ int scale_exp_from_amax(unsigned bits) {
   return e;
 }
 
-template <int W>
+template <int W, int BM_ = 256>
 struct H2Geom {
-  static constexpr int BM = 256, BN = 128;
+  static constexpr int BM = BM_, BN = 128;
   static constexpr int R = BM / W, RI = R < W ? R : W, NI = R / RI, HR = RI + 2, HC = W + 2;
   static constexpr int PXB = 48;  // bytes per staged pixel and plane: 16 halfs + 8 pad (odd multiple of 16 B: conflict-free b128)
   // row pitch: the 32 lanes of a fragment read are 32 consecutive output pixels; for W < 32 they span several rows and the
@@ -75,18 +75,21 @@ struct H2Geom {
   static constexpr int PLANE_B = NI * HR * RPB, ABUF_B = 2 * PLANE_B;
   static constexpr int NS = 3, SLOT_B = 8192, BOFF = 2 * ABUF_B;
   static constexpr int LDS_B = BOFF + NS * SLOT_B;
-  static constexpr int P = NI * HR * HC, ITEMS = P * 4, NT = 512, NST = (ITEMS + NT - 1) / NT;
+  static constexpr int NT = 2 * BM;      // 8 waves for a 256-pixel tile (one block per CU), 4 for 128 (two independent blocks per CU)
+  static constexpr int PPW = 512 / NT;   // 1-KB weight-DMA pieces per wave and tap (8 per tap)
+  static constexpr int P = NI * HR * HC, ITEMS = P * 4, NST = (ITEMS + NT - 1) / NT;
   static_assert(RPB >= HC * PXB && (W == 32 || (RPB - W * PXB) % 256 == 0), "row pitch");
   static_assert(LDS_B <= 160 * 1024, "LDS");
 };
 
-template <int W, int PRE>
-__global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
-  using G = H2Geom<W>;
+template <int W, int PRE, int BM_ = 256>
+__global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) {
+  using G = H2Geom<W, BM_>;
+  constexpr int PPW = G::PPW;
   constexpr int BM = G::BM, BN = G::BN, RI = G::RI, NI = G::NI, HR = G::HR, HC = G::HC, PXB = G::PXB, RPB = G::RPB;
   constexpr int PLANE_B = G::PLANE_B, ABUF_B = G::ABUF_B, BOFF = G::BOFF, SLOT_B = G::SLOT_B;
   constexpr int ITEMS = G::ITEMS, NT = G::NT, NST = G::NST;
-  static_assert(NST == 3 || NST == 4, "staging passes");
+  static_assert(NST >= 3 && NST <= 5, "staging passes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,12 +154,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
     }
   };
   // s_waitcnt vmcnt(N) that also pins the staging registers (N literal)
-#define FL_STAGE_WAIT(N)                                                                                         \
-  do {                                                                                                           \
-    if constexpr (NST == 3)                                                                                      \
-      asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2])::"memory");              \
-    else                                                                                                         \
-      asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[NST - 1])::"memory"); \
+#define FL_STAGE_WAIT(N)                                                                                                      \
+  do {                                                                                                                        \
+    if constexpr (NST == 3)                                                                                                   \
+      asm volatile("s_waitcnt vmcnt(%3)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]) : "i"(N) : "memory");                      \
+    else if constexpr (NST == 4)                                                                                              \
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[NST > 3 ? 3 : 0]) : "i"(N) : "memory"); \
+    else                                                                                                                      \
+      asm volatile("s_waitcnt vmcnt(%5)"                                                                                      \
+                   : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[NST > 3 ? 3 : 0]), "+v"(stg[NST > 4 ? 4 : 0])           \
+                   : "i"(N) : "memory");                                                                                      \
   } while (0)
   // one staging item: pre-op + split + two ds_write_b64 (~65 VALU instructions). Items are spread over the taps after the
   // halo loads have landed and issued INSIDE those taps' MFMA clusters (sched_group_barrier interleave): done in one piece
@@ -190,6 +197,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
     stage_item(std::integral_constant<int, 1>{}, buf, c);
     stage_item(std::integral_constant<int, 2>{}, buf, c);
     stage_item(std::integral_constant<int, 3>{}, buf, c);
+    stage_item(std::integral_constant<int, 4>{}, buf, c);
   };
 
   // ---- A fragment addresses (bytes inside a plane): tile row r -> halo pixel of tap (0,0); tap (dy,dx) adds dy*RPB + dx*PXB
@@ -206,14 +214,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
   // ---- B ring: tap (c, t) -> global fragments [g16 = t * nC + c][32-col tile][piece][lane] x 16 B; this wave moves the
   // wid-th KB of the tap's 8 KB
   const int nt32 = g.Cout >> 5;
-  const char* wsrc = g.wpack + H2_HDR + ((size_t)(tile_n0 >> 5) * 128 + wid * 64 + lane) * 16;
+  const char* wsrc = g.wpack + H2_HDR + ((size_t)(tile_n0 >> 5) * 128 + wid * PPW * 64 + lane) * 16;
   const size_t g16_stride = (size_t)nt32 * 128 * 16;
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  auto dma_tap = [&](int c, int t, int slot) {
+  auto dma_tap = [&](int c, int t, int slot) {  // this wave's PPW of the tap's eight 1-KB pieces
     const int cc = c < nC ? c : nC - 1;  // past the end: a harmless reload into a slot nobody reads
     const char* src = wsrc + (size_t)(t * nC + cc) * g16_stride;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + BOFF + slot * SLOT_B + wid * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < PPW; ++q)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + q * 1024), (lptr_t)(smem + BOFF + slot * SLOT_B + (wid * PPW + q) * 1024), 16, 0, 0);
   };
 
   struct Frags {
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
   dma_tap(0, 0, 0);
   dma_tap(0, 1, 1);
   dma_tap(0, 2, 2);
-  FL_STAGE_WAIT(3);
+  FL_STAGE_WAIT(3 * PPW);
   stage_store(0, 0);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -293,11 +303,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_h2_kernel(const H2Args g) {
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (T == 0 || T == 1) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST + 1) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST + PPW) : "memory");
     } else if constexpr (T == 2) {
-      FL_STAGE_WAIT(1);  // the halo loads of tap 0 are older than DMA(t+2): now complete
+      FL_STAGE_WAIT(PPW);  // the halo loads of tap 0 are older than DMA(t+2): now complete
     } else {
-      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) as a builtin: hipcc then knows the fragment reads have landed
     __builtin_amdgcn_s_barrier();
@@ -691,10 +701,28 @@ __global__ void h2_pack_kernel(const float* __restrict__ w, char* __restrict__ o
 
 template <int W>
 void h2_set_attr() {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int mx = 160 * 1024;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 0, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 0, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+}
+
+// M-tile of the 3x3 kernel: 256 pixels (8 waves, one block per CU) or 128 (4 waves; two INDEPENDENT blocks per CU, whose
+// prologues / epilogues / barriers overlap each other's MFMA clusters). FL_H2_BM overrides the per-shape default.
+int h2_bm(int W, int Cin, bool pre, long long M) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("FL_H2_BM"); forced = e ? atoi(e) : 0; }
+  int bm = forced ? forced : 256;
+  if (bm == 128) {  // two blocks must fit the CU's LDS
+    const int ni = (128 / W) > W ? (128 / W) / W : 1;
+    const int lds = (W == 32 ? H2Geom<32, 128>::LDS_B : W == 16 ? H2Geom<16, 128>::LDS_B : H2Geom<8, 128>::LDS_B) + (pre ? 2 * ni * Cin * 4 : 0);
+    if (2 * lds > 160 * 1024) bm = 256;
+  }
+  if (M % bm) bm = (M % 128 == 0) ? 128 : 256;
+  return bm;
 }
 
 }  // namespace
@@ -704,7 +732,7 @@ namespace fl {
 bool conv3x3_h2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
   if (Cin % 32 || Cout % 128 || (reinterpret_cast<uintptr_t>(x) & 15) || H != W) return false;
   if ((long long)B * H * W * Cin >= (1ll << 31)) return false;
-  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && (W == 8 || W == 16 || W == 32)) return ((long long)B * H * W) % 256 == 0;
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && (W == 8 || W == 16 || W == 32)) return ((long long)B * H * W) % 128 == 0;
   return false;
 }
 
@@ -716,8 +744,8 @@ bool conv4x4s2_h2_applicable(const float* x, int B, int H, int W, int Cin, int C
 }
 
 // bytes of the pre-op coefficient block ([scale | shift][images per tile][Cin]) behind the kernel's static LDS layout
-static int h2_pre_bytes(int ksize, int Wout, int Cin) {
-  const int ni = (256 / Wout) > Wout ? (256 / Wout) / Wout : 1;
+static int h2_pre_bytes(int ksize, int Wout, int Cin, int bm = 256) {
+  const int ni = (bm / Wout) > Wout ? (bm / Wout) / Wout : 1;
   return 2 * ni * Cin * (int)sizeof(float);
 }
 
@@ -734,20 +762,26 @@ int launch_conv_h2(const float* x, const void* wpack, const float* bias, float* 
                    int act, float act_param, hipStream_t s) {
   H2Args g;
   g.pre_scale = pre_scale; g.pre_shift = pre_shift;
-  const int pre_b = pre_scale ? h2_pre_bytes(ksize, ksize == 3 ? W : W / 2, Cin) : 0;
-  g.x = x; g.wpack = reinterpret_cast<const char*>(wpack); g.bias = bias; g.y = y; g.stats = stats;
-  g.a_amax = a_amax; g.a_exp = a_exp;
   g.Cin = Cin; g.Cout = Cout; g.tiles_n = Cout / 128; g.act = act; g.act_param = act_param;
+  g.a_amax = a_amax; g.a_exp = a_exp;
+  g.x = x; g.wpack = reinterpret_cast<const char*>(wpack); g.bias = bias; g.y = y; g.stats = stats;
   g.M = ksize == 3 ? B * H * W : B * (H / 2) * (W / 2);
-  g.ntiles = (g.M / 256) * g.tiles_n;
+  const int bm = ksize == 3 ? h2_bm(W, Cin, pre_scale != nullptr, g.M) : 256;
+  const int pre_b = pre_scale ? h2_pre_bytes(ksize, ksize == 3 ? W : W / 2, Cin, bm) : 0;
+  g.ntiles = (g.M / bm) * g.tiles_n;
   const int blocks = g.ntiles;
   static std::once_flag once;
   std::call_once(once, [] { h2_set_attr<32>(); h2_set_attr<16>(); h2_set_attr<8>(); });
   const int prio = g.pre_scale != nullptr;  // template PRE
-#define FL_LAUNCH(WW)                                                                                              \
-  do {                                                                                                             \
-    if (prio) hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 1>), dim3(blocks), dim3(512), H2Geom<WW>::LDS_B + pre_b, s, g);    \
-    else hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 0>), dim3(blocks), dim3(512), H2Geom<WW>::LDS_B + pre_b, s, g);         \
+#define FL_LAUNCH(WW)                                                                                                       \
+  do {                                                                                                                      \
+    if (bm == 256) {                                                                                                        \
+      if (prio) hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 1, 256>), dim3(blocks), dim3(512), (H2Geom<WW, 256>::LDS_B + pre_b), s, g); \
+      else hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 0, 256>), dim3(blocks), dim3(512), (H2Geom<WW, 256>::LDS_B + pre_b), s, g);      \
+    } else {                                                                                                                \
+      if (prio) hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 1, 128>), dim3(blocks), dim3(256), (H2Geom<WW, 128>::LDS_B + pre_b), s, g); \
+      else hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 0, 128>), dim3(blocks), dim3(256), (H2Geom<WW, 128>::LDS_B + pre_b), s, g);      \
+    }                                                                                                                       \
   } while (0)
 #define FL_LAUNCH4(WW)                                                                                               \
   do {                                                                                                             \
