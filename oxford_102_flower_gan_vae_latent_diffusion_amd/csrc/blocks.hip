@@ -121,10 +121,10 @@ __global__ void res_tail_out_kernel(const float* __restrict__ y, const float* __
       u.x *= att; u.y *= att; u.z *= att; u.w *= att;
       if (xres) {
         float4 r = ld4(xres + off);
-        if (xs) {  // the residual before its LayerNorm2d-apply + Swish (same expression as affine_act_kernel)
+        if (xs) {  // the residual before its LayerNorm2d-apply + Swish (the fused inference path: fast Swish, as in conv_h2.hip)
           const float4 a = ld4(xs + (long long)b * C + c4 * 4), d = ld4(xh + (long long)b * C + c4 * 4);
-          r.x = fl::swish_acc(r.x * a.x + d.x); r.y = fl::swish_acc(r.y * a.y + d.y);
-          r.z = fl::swish_acc(r.z * a.z + d.z); r.w = fl::swish_acc(r.w * a.w + d.w);
+          r.x = fl::swish_fast(r.x * a.x + d.x); r.y = fl::swish_fast(r.y * a.y + d.y);
+          r.z = fl::swish_fast(r.z * a.z + d.z); r.w = fl::swish_fast(r.w * a.w + d.w);
         }
         u.x += r.x; u.y += r.y; u.z += r.z; u.w += r.w;
       }

@@ -54,8 +54,7 @@ struct H2Args {
   float act_param;
 };
 
-// x * sigmoid(x) on the fast transcendental pipe (v_exp_f32 + v_rcp_f32: a few ulp, far inside the parity tolerance)
-__device__ __forceinline__ float swish_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+using fl::swish_fast;
 
 __device__ __forceinline__ int scale_exp_from_amax(unsigned bits) {
   const int E = (int)((bits >> 23) & 0xffu);

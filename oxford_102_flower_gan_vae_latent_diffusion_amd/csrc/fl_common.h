@@ -28,6 +28,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // accurate sigmoid (expf, not the fast intrinsic) – used where parity matters
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float swish_acc(float x) { return x * sigmoid_acc(x); }
+// x * sigmoid(x) on the fast transcendental pipe (v_exp_f32 + v_rcp_f32: a few ulp, far inside the parity tolerance): the
+// inference-side streaming kernels, where the accurate expf makes a bandwidth-bound pass ALU-bound
+__device__ __forceinline__ float swish_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 // d/dx [x*sigmoid(x)] = s*(1 + x*(1-s))
 __device__ __forceinline__ float swish_grad(float x) {
   float s = sigmoid_acc(x);
