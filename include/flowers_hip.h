@@ -389,6 +389,30 @@ int fl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float
  *                    x <- (x - (1-a_t)/sqrt(1-ab_t)*eps)/sqrt(a_t) + [t>0] sqrt(beta_t)*z, t = *(int64*)aux[2], tables
  *                    W[0..2] = alpha, alpha_bar, beta; z = A[2] if given, else Philox4x32-10 N(0,1) with seed
  *                    (K[0] | K[1]<<32) and counter *(int64*)aux[0] + i/4 (the stream fl_philox_fill would produce).
+ *   Training kinds (the denoiser's backward, loss and optimizer: v2:1260-1264 as two persistent launches):
+ *   FL_PJOB_GEMM flags (field `flags`): FL_PG_TA / FL_PG_TW = operand A / W is stored with the contraction index as
+ *                    its memory ROW: A_s[k*lda + m], W_s[k*ldw + n]  (dgrad: dx = dy * W is {A = dy, W = weight, TW};
+ *                    wgrad: dW = dy^T x is {A = dy, W = x, TA|TW, K = batch}); FL_PG_COLSUM (with TA): the tiles of
+ *                    column 0 also emit aux[0][m] = alpha * (1 + sigmoid(*gate) if gate) * sum_k A[k][m] (the bias
+ *                    gradient rides on the weight gradient); FL_PG_ACTBWD: v *= act'(aux[1][row*ld2 + col]) after the
+ *                    bias (act names the activation whose derivative is taken; no forward activation is applied);
+ *                    aux[3] != 0: the pre-activation value is stored there too (row stride ldc).
+ *   FL_PJOB_LNBWD    row LayerNorm backward: x = A[0], dy = A[1]; u = mask*(xhat*W[0]+bias[0]); gl = dy*act'(u)*mask;
+ *                    C = rstd*(gl*w - mean(gl*w) - xhat*mean(gl*w*xhat)) + R; aux[0] = gl (optional), aux[1] = [M][2]
+ *                    (mean, rstd) recomputed from x exactly as FL_PJOB_ROWNORM computes them.
+ *   FL_PJOB_LNCOL    C[n] = sum_m gl[m][n]*(x[m][n]-mean_m)*rstd_m, aux[0][n] = sum_m gl[m][n]; gl = A[0], x = A[1],
+ *                    stats = aux[1]  (LayerNorm weight / bias gradients, 32 columns per tile).
+ *   FL_PJOB_LOSS     rows of euclidean_distance_loss (v2:293-302) and its gradient: d = A[0]-A[1]; aux[0][m] =
+ *                    sqrt(sum d^2 + 1e-8); C = alpha*d/norm; aux[1][m] = sum_n C[m][n]*A[2][m][n].
+ *   FL_PJOB_FIN      one tile: C[0] = mean(A[0][0..M)); aux[0][0] = s(1-s)*sum(A[1][0..M)), s = sigmoid(*gate).
+ *   FL_PJOB_EWADD    C = A[0] + A[1] (+ A[2]).
+ *   FL_PJOB_EMBBWD   C[r][:] = sum over b with idx[b] == r of A[0][b][:]  (idx = (int64*)W[0], K[0] = table rows, M = batch).
+ *   FL_PJOB_SQNORM   C[t] = sum of squares of tile t's slice of A[0][0..K[0])  (256 tiles).
+ *   FL_PJOB_ADAM     clip_grad_norm_ + Adam/AdamW (torch semantics) on the flat buffers: every tile sums the 256 partials
+ *                    W[0] -> norm = alpha*sqrt(.), coef = min(1, bias_scale[2]/(norm+1e-6)); g' = g*alpha*coef; step =
+ *                    *(int*)W[2] + 1 (bump it with fl_program_post); p = C, g = A[0], m = aux[0], v = aux[1], lr = *W[1],
+ *                    b1, b2 = bias_scale[0..1], eps, weight decay = eps2 (decoupled iff flags & FL_PG_DECOUPLED);
+ *                    tile 0 stores coef -> aux[2], norm -> aux[3].
  * GEMM jobs may pick bias[0] from a table: when aux[2] != 0 the row *(int64*)aux[2] of stride bias_row_stride is
  * used (time-dependent terms of the sampler, precomputed for every timestep).
  * Pointer fields hold a device address, 0 (none), or a small integer 1..FL_PROG_MAX_IO naming slot (value-1) of the
@@ -396,7 +420,10 @@ int fl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float
  * ------------------------------------------------------------------------ */
 #define FL_PROG_MAX_IO 16
 #define FL_PROG_MAX_SEG 3
-enum { FL_PJOB_GEMM = 0, FL_PJOB_ROWNORM = 1, FL_PJOB_SINUSOID = 2, FL_PJOB_GATHER = 3, FL_PJOB_PSAMPLE = 4 };
+enum { FL_PJOB_GEMM = 0, FL_PJOB_ROWNORM = 1, FL_PJOB_SINUSOID = 2, FL_PJOB_GATHER = 3, FL_PJOB_PSAMPLE = 4,
+       FL_PJOB_LNBWD = 5, FL_PJOB_LNCOL = 6, FL_PJOB_LOSS = 7, FL_PJOB_FIN = 8, FL_PJOB_EWADD = 9, FL_PJOB_EMBBWD = 10,
+       FL_PJOB_SQNORM = 11, FL_PJOB_ADAM = 12 };
+enum { FL_PG_TA = 1, FL_PG_TW = 2, FL_PG_COLSUM = 4, FL_PG_ACTBWD = 8, FL_PG_DECOUPLED = 16 };
 typedef struct fl_pjob {
   uint64_t A[FL_PROG_MAX_SEG], W[FL_PROG_MAX_SEG], bias[FL_PROG_MAX_SEG];
   uint64_t R, C, mask, gate;
@@ -407,8 +434,10 @@ typedef struct fl_pjob {
   int32_t tile_begin, ntiles; /* tiles of this job inside its phase: [tile_begin, tile_begin + ntiles) */
   float bias_scale[FL_PROG_MAX_SEG];
   float eps, eps2;
-  int32_t bias_row_stride, pad_;
-} fl_pjob; /* 240 bytes, no implicit padding */
+  int32_t bias_row_stride, flags;
+  float alpha;
+  int32_t ld2, pad_[2];
+} fl_pjob; /* 256 bytes (one 32-bit word per lane of a wave), no implicit padding */
 /* Counters bumped once per run, after the last phase, by the last block to leave (the device-resident DDPM step
  * counter in its int32 and int64 forms, the Philox offset): ptr == 0 entries are skipped. */
 typedef struct fl_program_post {
@@ -426,13 +455,13 @@ typedef struct fl_pphase {
 int fl_program_job_bytes(void);
 int fl_program_phase_bytes(void);
 /* tiles a job occupies = ceil(M/32) row tiles x tiles per row tile (GEMM: N/32; ROWNORM: 8; SINUSOID: ceil(32*N/2/256);
- * GATHER, PSAMPLE: ceil(32*N/4/256));
+ * GATHER, PSAMPLE, EWADD: ceil(32*N/4/256); LNBWD, LOSS: 8; LNCOL: N/32, EMBBWD: K[0], FIN: 1, SQNORM, ADAM: 256 in all);
  * negative fl_status if the job violates the shape rules above. `job` is a HOST pointer. */
 int fl_program_job_tiles(const void* job);
 /* Bytes of the barrier area `sync` (arrival counters spread over memory channels, departures, abort flag). */
 int fl_program_sync_bytes(void);
 #define FL_PROG_SYNC_ABORT_WORD (8 * 1024 + 16) /* uint32 index inside `sync`: != 0 after a run = a barrier timed out */
-/* Run a device-resident program (n_phases*16 + n_jobs*240 bytes <= 24 KiB: it is copied to LDS). `io`: HOST array of
+/* Run a device-resident program (n_phases*16 + n_jobs*256 bytes <= 29.5 KiB: it is copied to LDS). `io`: HOST array of
  * n_io device pointers (read at call time). `sync`: fl_program_sync_bytes() zeroed device bytes owned by the caller,
  * reused across runs (abort word != 0 afterwards: the run is void and the caller must zero `sync`). max_blocks: 0 =
  * one block per CU. Concurrent runs must not share `sync`; two programs running at once on one device may each wait

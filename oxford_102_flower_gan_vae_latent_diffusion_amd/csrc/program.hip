@@ -31,7 +31,7 @@ constexpr int KC = 256;            // k values per block chunk (64 per wave)
 constexpr int LDK = KC + 4;        // LDS row stride of a chunk image (floats)
 constexpr int STAGE = 2 * TS * LDK;  // floats per LDS stage: 32 A rows then 32 W rows
 constexpr int SLD = 36;            // LDS row stride of a partial output tile (floats)
-constexpr int PROG_LDS_BYTES = 24 * 1024;  // LDS copy of the program (phases + jobs)
+constexpr int PROG_LDS_BYTES = 30 * 1024 - 512;  // LDS copy of the program (phases + jobs); 512 bytes left for the statics
 constexpr int LDS_BYTES = 2 * STAGE * 4 + PROG_LDS_BYTES;
 constexpr int NCTR = 8;            // arrival counters
 constexpr int CTR_STRIDE = 1024;   // ... this many uints apart (4 KB)
@@ -83,12 +83,20 @@ __device__ __forceinline__ void st1g(float* p, float v) {
   if constexpr (WT) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
   else *(__attribute__((address_space(1))) float*)(p) = v;
 }
+// Row scalars (LayerNorm statistics, loss norms, sum-of-squares partials) are 4-8 byte items that DIFFERENT blocks write into
+// one cache line: a block whose XCD wrote part of such a line may keep a copy of it in its L2 whose other bytes are stale.
+// Consumers read them with agent-scope loads (sc1: served coherently, never from a stale L2 copy), like the barrier counters.
+__device__ __forceinline__ float ld1c(const float* p) {
+  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ long long ldi64g(const long long* p) { return *(__attribute__((address_space(1))) const long long*)(p); }
 template <bool WT>
 __device__ __forceinline__ void st4g(float* p, const float4& v) {
   f32x4v t;
   t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
-  if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+  // (a VMEM store of more than 64 bits reads its data registers AFTER issue: a VALU write to them needs 2 wait states on
+  // gfx940+. hipcc's hazard recognizer inserts those for its own stores but cannot see inside inline asm: s_nop 1.)
+  if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
   else *(gf4w_t*)(p) = t;
 }
 
@@ -136,6 +144,9 @@ __device__ __forceinline__ void load_job(const int* src /* LDS */, fl_pjob& d) {
   d.eps = ldsf(p, FL_JW(eps));
   d.eps2 = ldsf(p, FL_JW(eps2));
   d.bias_row_stride = ldsi(p, FL_JW(bias_row_stride));
+  d.flags = ldsi(p, FL_JW(flags));
+  d.alpha = ldsf(p, FL_JW(alpha));
+  d.ld2 = ldsi(p, FL_JW(ld2));
 }
 
 // ---------------------------------------------------------------------------------------------- GEMM tile
@@ -143,11 +154,24 @@ struct Stage {
   f32x4v a[8], w[8];
 };
 
-template <bool WT>
+__device__ __forceinline__ float act_grad(float u, int act) {
+  switch (act) {
+    case FL_ACT_SWISH: return fl::swish_grad(u);
+    case FL_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case FL_ACT_SIGMOID: { const float sg = fl::sigmoid_acc(u); return sg * (1.f - sg); }
+    default: return 1.f;
+  }
+}
+
+// TA / TW: the operand is stored with the contraction index as its memory row (FL_PG_TA / FL_PG_TW): its chunk image in
+// LDS is then [256 k][32] (a wave's loads and ds_write_b128 cover 8 rows x 128 B, fragments are 64 consecutive floats
+// per ds_read_b32: both conflict-free) instead of [32][256 + 4].
+template <bool WT, bool TA, bool TW>
 __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, const ProgIO& io, float* smem) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
   const int kq4 = lane * 4;  // this thread's k offset inside a chunk row (a wave covers one whole 256-wide row slice)
+  const int tr = threadIdx.x >> 3, tc4 = (threadIdx.x & 7) * 4;  // transposed operands: chunk rows tr + 32 i, 4 columns
 
   // chunk bookkeeping (all scalar): segment s owns chunks [cb_s, cb_{s+1})
   const float* A0 = rp(jb.A[0], io);
@@ -169,11 +193,12 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
   const int lda0 = jb.lda[0], lda1 = jb.lda[1], lda2 = jb.lda[2];
   const int ldw0 = jb.ldw[0], ldw1 = jb.ldw[1], ldw2 = jb.ldw[2];
   const int r0 = rt * TS + w, n0 = ct * TS + w;  // this thread loads rows r0 + 4i (A) and n0 + 4i (W), i < 8
+  const int am0 = rt * TS + tc4, wn0 = ct * TS + tc4;  // ... or these columns of rows k (transposed operands)
   const int Mm1 = jb.M - 1;
 
   // global -> registers for chunk c (clamped: a surplus stage re-reads the last chunk and is never consumed);
-  // returns whether this thread's 16-byte column lies inside the chunk's valid k range
-#define FL_ISSUE(RS, cidx, okvar)                                                                  \
+  // okvar: this thread's 16-byte column lies inside the chunk's valid k range; kvvar: valid k rows of the chunk
+#define FL_ISSUE(RS, cidx, okvar, kvvar)                                                           \
   do {                                                                                             \
     int c_ = (cidx);                                                                               \
     c_ = c_ < nC ? c_ : nC - 1;                                                                    \
@@ -185,42 +210,80 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
     const int Ks_ = s2_ ? K2 : (s1_ ? K1 : K0);                                                    \
     const int kk_ = (c_ - (s2_ ? c2 : (s1_ ? c1 : 0))) * KC;                                       \
     okvar = kk_ + kq4 < Ks_;                                                                       \
+    kvvar = Ks_ - kk_;                                                                             \
     const int kcol_ = okvar ? kk_ + kq4 : kk_;                                                     \
     /* 32-bit element offsets from a scalar base (validated: rows*ld < 2^30): full-rate 24-bit multiplies */       \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                             \
-      int ar_ = r0 + 4 * i_;                                                                       \
-      ar_ = ar_ < Mm1 ? ar_ : Mm1;                                                                 \
-      RS.a[i_] = ld4gv(Ab_ + (size_t)(__umul24((unsigned)ar_, (unsigned)lda_) + (unsigned)kcol_)); \
+    if constexpr (TA) {                                                                            \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                           \
+        int kr_ = kk_ + tr + 32 * i_;                                                              \
+        kr_ = kr_ < Ks_ ? kr_ : Ks_ - 1;                                                           \
+        RS.a[i_] = ld4gv(Ab_ + (size_t)(__umul24((unsigned)kr_, (unsigned)lda_) + (unsigned)am0)); \
+      }                                                                                            \
+    } else {                                                                                       \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                           \
+        int ar_ = r0 + 4 * i_;                                                                     \
+        ar_ = ar_ < Mm1 ? ar_ : Mm1;                                                               \
+        RS.a[i_] = ld4gv(Ab_ + (size_t)(__umul24((unsigned)ar_, (unsigned)lda_) + (unsigned)kcol_)); \
+      }                                                                                            \
     }                                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                               \
-      RS.w[i_] = ld4gv(Wb_ + (size_t)(__umul24((unsigned)(n0 + 4 * i_), (unsigned)ldw_) + (unsigned)kcol_)); \
+    if constexpr (TW) {                                                                            \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                           \
+        int kr_ = kk_ + tr + 32 * i_;                                                              \
+        kr_ = kr_ < Ks_ ? kr_ : Ks_ - 1;                                                           \
+        RS.w[i_] = ld4gv(Wb_ + (size_t)(__umul24((unsigned)kr_, (unsigned)ldw_) + (unsigned)wn0)); \
+      }                                                                                            \
+    } else {                                                                                       \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                             \
+        RS.w[i_] = ld4gv(Wb_ + (size_t)(__umul24((unsigned)(n0 + 4 * i_), (unsigned)ldw_) + (unsigned)kcol_)); \
+    }                                                                                              \
   } while (0)
 
-  // registers -> LDS stage (row images [32][LDK] for A, then W); out-of-range columns become zeros
-#define FL_PARK(RS, okvar, st)                                                                     \
+  // registers -> LDS stage (A image, then W image at TS*LDK); out-of-range k become zeros
+#define FL_PARK(RS, okvar, kvvar, st)                                                              \
   do {                                                                                             \
-    float* La_ = smem + (st) * STAGE + w * LDK + kq4;                                              \
-    float* Lw_ = La_ + TS * LDK;                                                                   \
+    float* Ia_ = smem + (st) * STAGE;                                                              \
+    float* Iw_ = Ia_ + TS * LDK;                                                                   \
     const f32x4v z_ = {0.f, 0.f, 0.f, 0.f};                                                        \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                             \
-      *(lf4_t*)(La_ + 4 * i_ * LDK) = okvar ? RS.a[i_] : z_;                                       \
-      *(lf4_t*)(Lw_ + 4 * i_ * LDK) = okvar ? RS.w[i_] : z_;                                       \
+      if constexpr (TA) *(lf4_t*)(Ia_ + (tr + 32 * i_) * TS + tc4) = tr + 32 * i_ < kvvar ? RS.a[i_] : z_; \
+      else *(lf4_t*)(Ia_ + (w + 4 * i_) * LDK + kq4) = okvar ? RS.a[i_] : z_;                      \
+      if constexpr (TW) *(lf4_t*)(Iw_ + (tr + 32 * i_) * TS + tc4) = tr + 32 * i_ < kvvar ? RS.w[i_] : z_; \
+      else *(lf4_t*)(Iw_ + (w + 4 * i_) * LDK + kq4) = okvar ? RS.w[i_] : z_;                      \
     }                                                                                              \
   } while (0)
 
-  // each wave contracts its 64-wide k slice of the parked chunk: 2 x (8 ds_read_b128 + 16 MFMA)
+  // each wave contracts its 64-wide k slice of the parked chunk: 16 ds_read_b128 (or 4 x ds_read_b32 each) + 32 MFMA;
+  // MFMA (q, e) of lane half lh takes k = 64 w + 32 (q>>2) + 16 lh + 4 (q&3) + e from both operands
 #define FL_CONTRACT(st)                                                                            \
   do {                                                                                             \
-    const float* Fa_ = smem + (st) * STAGE + lr * LDK + 64 * w + 16 * lh;                          \
-    const float* Fw_ = Fa_ + TS * LDK;                                                             \
-    f32x4v fa_[8], fw_[8]; /* all 16 fragment reads in flight before the first MFMA */            \
+    const float* Ia_ = smem + (st) * STAGE;                                                        \
+    const float* Iw_ = Ia_ + TS * LDK;                                                             \
+    f32x4v fa_[8], fw_[8]; /* all fragment reads in flight before the first MFMA */               \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                             \
-      fa_[q_] = *(const lf4_t*)(Fa_ + 32 * (q_ >> 2) + 4 * (q_ & 3));                              \
-      fw_[q_] = *(const lf4_t*)(Fw_ + 32 * (q_ >> 2) + 4 * (q_ & 3));                              \
+      const int kb_ = 64 * w + 32 * (q_ >> 2) + 16 * lh + 4 * (q_ & 3);                            \
+      if constexpr (TA) {                                                                          \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) fa_[q_][e_] = *(const lf1_t*)(Ia_ + (kb_ + e_) * TS + lr); \
+      } else fa_[q_] = *(const lf4_t*)(Ia_ + lr * LDK + kb_);                                      \
+      if constexpr (TW) {                                                                          \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) fw_[q_][e_] = *(const lf1_t*)(Iw_ + (kb_ + e_) * TS + lr); \
+      } else fw_[q_] = *(const lf4_t*)(Iw_ + lr * LDK + kb_);                                      \
     }                                                                                              \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                             \
       _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                             \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[q_][e_], fw_[q_][e_], acc, 0, 0, 0);        \
+    }                                                                                              \
+  } while (0)
+
+  // FL_PG_COLSUM (A transposed, column-0 tiles): sums over k of the parked A image, 8 row groups x 32 columns
+  const bool colsum = TA && (jb.flags & FL_PG_COLSUM) != 0 && ct == 0;
+  float cs = 0.f;
+#define FL_COLSUM(st)                                                                              \
+  do {                                                                                             \
+    if constexpr (TA) {                                                                            \
+      if (colsum) {                                                                                \
+        const float* Ia_ = smem + (st) * STAGE + (threadIdx.x >> 5) * 32 * TS + (threadIdx.x & 31); \
+        _Pragma("unroll 8") for (int j_ = 0; j_ < 32; ++j_) cs += *(const lf1_t*)(Ia_ + j_ * TS);  \
+      }                                                                                            \
     }                                                                                              \
   } while (0)
 
@@ -232,7 +295,7 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
   const int er = threadIdx.x >> 3, ec = (threadIdx.x & 7) * 4;
   const int gr = rt * TS + er, gc = ct * TS + ec;
   const int grc = gr < jb.M ? gr : jb.M - 1;
-  float4 e_b[FL_PROG_MAX_SEG], e_r = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 e_b[FL_PROG_MAX_SEG], e_r = make_float4(0.f, 0.f, 0.f, 0.f), e_p = make_float4(0.f, 0.f, 0.f, 0.f);
   float e_gate = 0.f, e_m = 1.f;
 #pragma unroll
   for (int s = 0; s < FL_PROG_MAX_SEG; ++s) {
@@ -244,29 +307,37 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
       e_b[s] = ld4g(bp);
     }
   }
+  const bool actbwd = (jb.flags & FL_PG_ACTBWD) != 0;
   if (jb.gate) e_gate = ld1g(rp(jb.gate, io));
   if (jb.mask) e_m = ld1g(rp(jb.mask, io) + (long long)grc * (jb.N / jb.mask_group) + gc / jb.mask_group);
   if (jb.R) e_r = ld4g(rp(jb.R, io) + (long long)grc * jb.ldr + gc);
+  if (actbwd) e_p = ld4g(rp(jb.aux[1], io) + (long long)grc * jb.ld2 + gc);
   Stage R0, R1;
   bool ok0, ok1;
+  int kv0, kv1;
   FL_STAMP(7);
-  FL_ISSUE(R0, 0, ok0);
-  FL_ISSUE(R1, 1, ok1);
+  FL_ISSUE(R0, 0, ok0, kv0);
+  FL_ISSUE(R1, 1, ok1, kv1);
   FL_STAMP(8);
   for (int c = 0; c < nC; c += 2) {
-    FL_PARK(R0, ok0, 0);
-    FL_ISSUE(R0, c + 2, ok0);
+    FL_PARK(R0, ok0, kv0, 0);
+    FL_ISSUE(R0, c + 2, ok0, kv0);
     __syncthreads();
     FL_CONTRACT(0);
+    FL_COLSUM(0);
     const bool more = c + 1 < nC;  // block-uniform
-    if (more) FL_PARK(R1, ok1, 1);
-    FL_ISSUE(R1, c + 3, ok1);
+    if (more) FL_PARK(R1, ok1, kv1, 1);
+    FL_ISSUE(R1, c + 3, ok1, kv1);
     __syncthreads();
-    if (more) FL_CONTRACT(1);
+    if (more) {
+      FL_CONTRACT(1);
+      FL_COLSUM(1);
+    }
   }
 #undef FL_ISSUE
 #undef FL_PARK
 #undef FL_CONTRACT
+#undef FL_COLSUM
   FL_STAMP(1);
 
   // meet in LDS: sm[w][row][col] (aliases stage 0; the loop's last barrier precedes every wave's last stage-0 read
@@ -275,14 +346,25 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
   float* mine = smem + w * (TS * SLD);
 #pragma unroll
   for (int r = 0; r < 16; ++r) *(lf1_t*)(mine + ((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + lr) = acc[r];
+  if constexpr (TA) {
+    if (colsum) *(lf1_t*)(smem + 4 * TS * SLD + threadIdx.x) = cs;  // [8 row groups][32 columns], behind the partial tiles
+  }
   __syncthreads();
   const float* s0 = smem + er * SLD + ec;
   f32x4v vv = *(const lf4_t*)(s0);
 #pragma unroll
   for (int k = 1; k < 4; ++k) vv += *(const lf4_t*)(s0 + k * (TS * SLD));
   float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+  const float gmul = jb.gate ? 1.f + fl::sigmoid_acc(e_gate) : 1.f;
+  if constexpr (TA) {
+    if (colsum && threadIdx.x < TS) {  // FL_PG_TA requires M % 32 == 0: every row of the tile exists
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += *(const lf1_t*)(smem + 4 * TS * SLD + g * TS + threadIdx.x);
+      st1g<WT>(wp(jb.aux[0], io) + rt * TS + threadIdx.x, jb.alpha * gmul * t);
+    }
+  }
   if (gr < jb.M) {
-    const float gmul = jb.gate ? 1.f + fl::sigmoid_acc(e_gate) : 1.f;
 #pragma unroll
     for (int s = 0; s < FL_PROG_MAX_SEG; ++s) {
       if (jb.bias[s]) {
@@ -290,10 +372,16 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
         v.x += sc * e_b[s].x; v.y += sc * e_b[s].y; v.z += sc * e_b[s].z; v.w += sc * e_b[s].w;
       }
     }
-    v.x = fl::apply_act(v.x, jb.act, 0.f);
-    v.y = fl::apply_act(v.y, jb.act, 0.f);
-    v.z = fl::apply_act(v.z, jb.act, 0.f);
-    v.w = fl::apply_act(v.w, jb.act, 0.f);
+    if (jb.aux[3]) st4g<WT>(wp(jb.aux[3], io) + (long long)gr * jb.ldc + gc, v);  // pre-activation copy (saved for backward)
+    if (actbwd) {
+      v.x *= act_grad(e_p.x, jb.act); v.y *= act_grad(e_p.y, jb.act);
+      v.z *= act_grad(e_p.z, jb.act); v.w *= act_grad(e_p.w, jb.act);
+    } else {
+      v.x = fl::apply_act(v.x, jb.act, 0.f);
+      v.y = fl::apply_act(v.y, jb.act, 0.f);
+      v.z = fl::apply_act(v.z, jb.act, 0.f);
+      v.w = fl::apply_act(v.w, jb.act, 0.f);
+    }
     if (jb.mask) {
       v.x *= e_m; v.y *= e_m; v.z *= e_m; v.w *= e_m;
     }
@@ -477,6 +565,339 @@ __device__ __forceinline__ void psample_tile(const fl_pjob& jb, int r0, int r1, 
   st4g<WT>(wp(jb.C, io) + i4 * 4, m);
 }
 
+// ---------------------------------------------------------------------------------------------- training kinds
+// Row LayerNorm backward (same arithmetic as layernorm_bwd_dx_kernel in norm.hip); mean / rstd are recomputed from the
+// saved input exactly as rownorm_tile computed them in the forward. One wave per row.
+template <bool WT>
+__device__ __forceinline__ void lnbwd_tile(const fl_pjob& jb, int row4, const ProgIO& io) {
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int row = row4 + w;
+  if (row >= jb.M) return;
+  const int D = jb.N, nv = D >> 8;
+  const float* x = rp(jb.A[0], io) + (long long)row * jb.lda[0];
+  const float* dy = rp(jb.A[1], io) + (long long)row * jb.lda[1];
+  const float* mk = jb.mask ? rp(jb.mask, io) + (long long)row * D : nullptr;
+  const float* R = jb.R ? rp(jb.R, io) + (long long)row * jb.ldr : nullptr;
+  const float* w1 = rp(jb.W[0], io);
+  const float* b1 = rp(jb.bias[0], io);
+  float4 v[4], g[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      v[i] = ld4g(x + (i * 64 + lane) * 4);
+      g[i] = ld4g(dy + (i * 64 + lane) * 4);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float m = fl::wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      const float a = v[i].x - m, b = v[i].y - m, c = v[i].z - m, d = v[i].w - m;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float r = 1.0f / sqrtf(fl::wave_sum(q) / D + jb.eps);
+  float s1 = 0.f, s2 = 0.f;
+  float* glo = jb.aux[0] ? wp(jb.aux[0], io) + (long long)row * jb.ldc : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      const int o = (i * 64 + lane) * 4;
+      const float4 ww = ld4g(w1 + o), bb = ld4g(b1 + o);
+      float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (mk) k = ld4g(mk + o);
+      float4 xh, gl;
+      xh.x = (v[i].x - m) * r; xh.y = (v[i].y - m) * r; xh.z = (v[i].z - m) * r; xh.w = (v[i].w - m) * r;
+      gl.x = g[i].x * act_grad(k.x * (xh.x * ww.x + bb.x), jb.act) * k.x;
+      gl.y = g[i].y * act_grad(k.y * (xh.y * ww.y + bb.y), jb.act) * k.y;
+      gl.z = g[i].z * act_grad(k.z * (xh.z * ww.z + bb.z), jb.act) * k.z;
+      gl.w = g[i].w * act_grad(k.w * (xh.w * ww.w + bb.w), jb.act) * k.w;
+      if (glo) st4g<WT>(glo + o, gl);
+      g[i].x = gl.x * ww.x; g[i].y = gl.y * ww.y; g[i].z = gl.z * ww.z; g[i].w = gl.w * ww.w;  // d xhat
+      v[i] = xh;
+      s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      s2 += (g[i].x * xh.x + g[i].y * xh.y) + (g[i].z * xh.z + g[i].w * xh.w);
+    }
+  }
+  const float t1 = fl::wave_sum(s1) / D, t2 = fl::wave_sum(s2) / D;
+  float* dx = wp(jb.C, io) + (long long)row * jb.ldc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      const int o = (i * 64 + lane) * 4;
+      float4 y;
+      y.x = r * (g[i].x - t1 - v[i].x * t2);
+      y.y = r * (g[i].y - t1 - v[i].y * t2);
+      y.z = r * (g[i].z - t1 - v[i].z * t2);
+      y.w = r * (g[i].w - t1 - v[i].w * t2);
+      if (R) {
+        const float4 k = ld4g(R + o);
+        y.x += k.x; y.y += k.y; y.z += k.z; y.w += k.w;
+      }
+      st4g<WT>(dx + o, y);
+    }
+  }
+  if (jb.aux[1] && lane == 0) {
+    float* st = wp(jb.aux[1], io) + 2 * (long long)row;
+    st1g<WT>(st, m);
+    st1g<WT>(st + 1, r);
+  }
+}
+
+// LayerNorm weight / bias gradients: 32 columns per tile, 8 row groups, LDS tree. The row statistics are staged in LDS
+// (coherent loads, one round trip) 1024 rows at a time.
+template <bool WT>
+__device__ __forceinline__ void lncol_tile(const fl_pjob& jb, int k, const ProgIO& io, float* smem) {
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const float* gl = rp(jb.A[0], io) + k * 32 + c;
+  const float* x = rp(jb.A[1], io) + k * 32 + c;
+  const float* st = rp(jb.aux[1], io);
+  float aw = 0.f, ab = 0.f;
+  for (int base = 0; base < jb.M; base += 1024) {
+    const int rows = jb.M - base < 1024 ? jb.M - base : 1024;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * rows; i += 256) *(lf1_t*)(smem + i) = ld1c(st + 2 * base + i);
+    __syncthreads();
+#pragma unroll 8
+    for (int m = rg; m < rows; m += 8) {
+      const float gv = ld1g(gl + (long long)(base + m) * jb.lda[0]), xv = ld1g(x + (long long)(base + m) * jb.lda[1]);
+      const float mu = *(const lf1_t*)(smem + 2 * m), rs = *(const lf1_t*)(smem + 2 * m + 1);
+      aw += gv * ((xv - mu) * rs);
+      ab += gv;
+    }
+  }
+  __syncthreads();
+  *(lf1_t*)(smem + threadIdx.x) = aw;
+  *(lf1_t*)(smem + 256 + threadIdx.x) = ab;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += *(const lf1_t*)(smem + which * 256 + g * 32 + c);
+    st1g<WT>(wp(which ? jb.aux[0] : jb.C, io) + k * 32 + c, t);
+  }
+  __syncthreads();
+}
+
+// euclidean_distance_loss rows (v2:293-302; euclid_norm_kernel / euclid_bwd_kernel of loss_optim.hip): one wave per row.
+template <bool WT>
+__device__ __forceinline__ void loss_tile(const fl_pjob& jb, int row4, const ProgIO& io) {
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int row = row4 + w;
+  if (row >= jb.M) return;
+  const int D = jb.N, nv = D >> 8;
+  const float* a = rp(jb.A[0], io) + (long long)row * jb.lda[0];
+  const float* b = rp(jb.A[1], io) + (long long)row * jb.lda[1];
+  const float* rr = jb.A[2] ? rp(jb.A[2], io) + (long long)row * jb.lda[2] : nullptr;
+  float4 d[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      const float4 p = ld4g(a + (i * 64 + lane) * 4), t = ld4g(b + (i * 64 + lane) * 4);
+      d[i] = make_float4(p.x - t.x, p.y - t.y, p.z - t.z, p.w - t.w);
+      s += (d[i].x * d[i].x + d[i].y * d[i].y) + (d[i].z * d[i].z + d[i].w * d[i].w);
+    }
+  }
+  const float nrm = sqrtf(fl::wave_sum(s) + 1e-8f);
+  float dot = 0.f;
+  float* out = wp(jb.C, io) + (long long)row * jb.ldc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      const int o = (i * 64 + lane) * 4;
+      float4 y;
+      y.x = jb.alpha * d[i].x / nrm; y.y = jb.alpha * d[i].y / nrm; y.z = jb.alpha * d[i].z / nrm; y.w = jb.alpha * d[i].w / nrm;
+      st4g<WT>(out + o, y);
+      if (rr) {
+        const float4 k = ld4g(rr + o);
+        dot += (y.x * k.x + y.y * k.y) + (y.z * k.z + y.w * k.w);
+      }
+    }
+  }
+  dot = fl::wave_sum(dot);
+  if (lane == 0) {
+    st1g<WT>(wp(jb.aux[0], io) + row, nrm);
+    if (jb.aux[1]) st1g<WT>(wp(jb.aux[1], io) + row, dot);
+  }
+}
+
+__device__ __forceinline__ float block_sum_lds(float v, float* smem) {
+  v = fl::wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) *(lf1_t*)(smem + (threadIdx.x >> 6)) = v;
+  __syncthreads();
+  const float t = (*(const lf1_t*)(smem) + *(const lf1_t*)(smem + 1)) + (*(const lf1_t*)(smem + 2) + *(const lf1_t*)(smem + 3));
+  __syncthreads();
+  return t;
+}
+
+// loss = mean of the row norms; gradient of the residual gate = s(1-s) * sum of the row dots (gate_grad_kernel)
+template <bool WT>
+__device__ __forceinline__ void fin_tile(const fl_pjob& jb, const ProgIO& io, float* smem) {
+  float a = 0.f, b = 0.f;
+  const float* n = rp(jb.A[0], io);
+  const float* d = jb.A[1] ? rp(jb.A[1], io) : nullptr;
+  for (int i = threadIdx.x; i < jb.M; i += 256) {
+    a += ld1c(n + i);
+    if (d) b += ld1c(d + i);
+  }
+  a = block_sum_lds(a, smem);
+  b = block_sum_lds(b, smem);
+  if (threadIdx.x == 0) {
+    st1g<WT>(wp(jb.C, io), a / jb.M);
+    if (d) {
+      const float sg = fl::sigmoid_acc(ld1g(rp(jb.gate, io)));
+      st1g<WT>(wp(jb.aux[0], io), sg * (1.f - sg) * b);
+    }
+  }
+}
+
+template <bool WT>
+__device__ __forceinline__ void ewadd_tile(const fl_pjob& jb, int r0, int r1, int k, const ProgIO& io) {
+  const int i = r0 * jb.N + (k * 256 + threadIdx.x) * 4;
+  if (i >= r1 * jb.N) return;
+  const int b = i / jb.N, d = i - b * jb.N;
+  float4 v = ld4g(rp(jb.A[0], io) + (long long)b * jb.lda[0] + d);
+  const float4 u = ld4g(rp(jb.A[1], io) + (long long)b * jb.lda[1] + d);
+  v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  if (jb.A[2]) {
+    const float4 t = ld4g(rp(jb.A[2], io) + (long long)b * jb.lda[2] + d);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  st4g<WT>(wp(jb.C, io) + (long long)b * jb.ldc + d, v);
+}
+
+// deterministic embedding gradient: tile = table row r; the batch's indices are walked from LDS, rows that match are added
+template <bool WT>
+__device__ __forceinline__ void embbwd_tile(const fl_pjob& jb, int r, const ProgIO& io, float* smem) {
+  const long long* idx = reinterpret_cast<const long long*>(rp(jb.W[0], io));
+  const float* src = rp(jb.A[0], io);
+  const int D = jb.N, nv = (D + 1023) >> 10;  // float4 per thread (D <= 4096)
+  float4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __attribute__((address_space(3))) int* li = (__attribute__((address_space(3))) int*)smem;
+  for (int b0 = 0; b0 < jb.M; b0 += 256) {
+    __syncthreads();
+    li[threadIdx.x] = b0 + (int)threadIdx.x < jb.M ? (int)ldi64g(idx + b0 + threadIdx.x) : -1;
+    __syncthreads();
+    const int nb = jb.M - b0 < 256 ? jb.M - b0 : 256;
+    for (int j = 0; j < nb; ++j) {
+      if (__builtin_amdgcn_readfirstlane(li[j]) == r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int o = (i * 256 + threadIdx.x) * 4;
+          if (i < nv && o < D) {
+            const float4 t = ld4g(src + (long long)(b0 + j) * jb.lda[0] + o);
+            acc[i].x += t.x; acc[i].y += t.y; acc[i].z += t.z; acc[i].w += t.w;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = (i * 256 + threadIdx.x) * 4;
+    if (i < nv && o < D) st4g<WT>(wp(jb.C, io) + (long long)r * jb.ldc + o, acc[i]);
+  }
+  __syncthreads();
+}
+
+constexpr int FLAT_TILES = 256;  // SQNORM / ADAM: the flat buffer is cut into this many slices
+__device__ __forceinline__ void flat_slice(int n, int t, int& lo, int& hi) {
+  const int per = ((n + FLAT_TILES - 1) / FLAT_TILES + 1023) & ~1023;  // multiple of 256 threads x float4
+  lo = t * per < n ? t * per : n;
+  hi = lo + per < n ? lo + per : n;
+}
+
+template <bool WT>
+__device__ __forceinline__ void sqnorm_tile(const fl_pjob& jb, int t, const ProgIO& io, float* smem) {
+  const float* g = rp(jb.A[0], io);
+  int lo, hi;
+  flat_slice(jb.K[0], t, lo, hi);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int i = lo + threadIdx.x * 4;
+  for (; i + 3 * 1024 + 3 < hi; i += 4096) {  // four float4 in flight
+    const float4 p = ld4g(g + i), q = ld4g(g + i + 1024), r = ld4g(g + i + 2048), u = ld4g(g + i + 3072);
+    a0 += (p.x * p.x + p.y * p.y) + (p.z * p.z + p.w * p.w);
+    a1 += (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+    a2 += (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w);
+    a3 += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
+  }
+  for (; i < hi; i += 1024) {  // n % 4 == 0 (validated): whole float4 only
+    const float4 p = ld4g(g + i);
+    a0 += (p.x * p.x + p.y * p.y) + (p.z * p.z + p.w * p.w);
+  }
+  const float tot = block_sum_lds((a0 + a1) + (a2 + a3), smem);
+  if (threadIdx.x == 0) st1g<WT>(wp(jb.C, io) + t, tot);
+}
+
+// clip_grad_norm_ + Adam / AdamW: adam_kernel of loss_optim.hip with the clip coefficient derived in every tile from
+// the SQNORM partials (the same 256 numbers summed in the same order: identical in every tile)
+__device__ __forceinline__ void adam_tile(const fl_pjob& jb, int t, const ProgIO& io, float* smem) {
+  const float part = ld1c(rp(jb.W[0], io) + threadIdx.x);  // FLAT_TILES == 256 threads
+  const float sq = block_sum_lds(part, smem);
+  const float gs = jb.alpha;
+  const float nrm = gs * sqrtf(sq);
+  const float maxn = jb.bias_scale[2];
+  float coef = 1.f;
+  if (maxn > 0.f) {
+    const float cf = maxn / (nrm + 1e-6f);
+    coef = cf < 1.f ? cf : 1.f;
+  }
+  if (t == 0 && threadIdx.x == 0) {
+    if (jb.aux[2]) *(__attribute__((address_space(1))) float*)wp(jb.aux[2], io) = coef;
+    if (jb.aux[3]) *(__attribute__((address_space(1))) float*)wp(jb.aux[3], io) = nrm;
+  }
+  const float lr = ld1g(rp(jb.W[1], io));
+  const float step = (float)(*(const __attribute__((address_space(1))) int*)rp(jb.W[2], io) + 1);
+  const float b1 = jb.bias_scale[0], b2 = jb.bias_scale[1], eps = jb.eps, wd = jb.eps2;
+  const float bc1 = 1.f - powf(b1, step);
+  const float bc2s = sqrtf(1.f - powf(b2, step));
+  const float cs = gs * coef;
+  const float step_size = lr / bc1;
+  const bool decoupled = (jb.flags & FL_PG_DECOUPLED) != 0;
+  const float decay = decoupled ? 1.f - lr * wd : 1.f;
+  const float l2 = decoupled ? 0.f : wd;
+  int lo, hi;
+  flat_slice(jb.K[0], t, lo, hi);
+  const float* g = rp(jb.A[0], io);
+  float* p = wp(jb.C, io);
+  float* m = wp(jb.aux[0], io);
+  float* v = wp(jb.aux[1], io);
+#define FL_ADAM1(G, P, Mv, Vv)                                   \
+  do {                                                           \
+    float gi_ = (G) * cs;                                        \
+    float pi_ = (P) * decay;                                     \
+    gi_ += l2 * (P);                                             \
+    const float mi_ = b1 * (Mv) + (1.f - b1) * gi_;              \
+    const float vi_ = b2 * (Vv) + (1.f - b2) * gi_ * gi_;        \
+    (Mv) = mi_;                                                  \
+    (Vv) = vi_;                                                  \
+    (P) = pi_ - step_size * (mi_ / (sqrtf(vi_) / bc2s + eps));   \
+  } while (0)
+  for (int i = lo + threadIdx.x * 4; i < hi; i += 2048) {  // two float4 of each of the four arrays in flight
+    const bool two = i + 1024 < hi;
+    const int j = two ? i + 1024 : i;
+    float4 g0 = ld4g(g + i), p0 = ld4g(p + i), m0 = ld4g(m + i), v0 = ld4g(v + i);
+    float4 g1 = ld4g(g + j), p1 = ld4g(p + j), m1 = ld4g(m + j), v1 = ld4g(v + j);
+    FL_ADAM1(g0.x, p0.x, m0.x, v0.x); FL_ADAM1(g0.y, p0.y, m0.y, v0.y);
+    FL_ADAM1(g0.z, p0.z, m0.z, v0.z); FL_ADAM1(g0.w, p0.w, m0.w, v0.w);
+    st4g<false>(p + i, p0); st4g<false>(m + i, m0); st4g<false>(v + i, v0);
+    if (two) {
+      FL_ADAM1(g1.x, p1.x, m1.x, v1.x); FL_ADAM1(g1.y, p1.y, m1.y, v1.y);
+      FL_ADAM1(g1.z, p1.z, m1.z, v1.z); FL_ADAM1(g1.w, p1.w, m1.w, v1.w);
+      st4g<false>(p + j, p1); st4g<false>(m + j, m1); st4g<false>(v + j, v1);
+    }
+  }
+#undef FL_ADAM1
+}
+
 // Device-wide barrier for a fully resident grid. Arrival counters sync[g*CTR_STRIDE] (g = block & 7; monotone over the
 // run), departures sync[NCTR*CTR_STRIDE], abort flag sync[NCTR*CTR_STRIDE + 16]. Returns false if the run is dead
 // (timeout here or in another block): every wave then leaves.
@@ -551,13 +972,22 @@ __device__ __forceinline__ bool xcd_barrier(unsigned* sync, int xcc, int slot, u
   return *s_ok != 0;
 }
 
-// tiles a job contributes per 32-row tile of the batch
+// tiles a job contributes per 32-row tile of its M rows; the kinds that are not laid out by row tiles count as ONE row tile
+__device__ __forceinline__ bool flat_kind(int kind) { return kind == FL_PJOB_LNCOL || kind >= FL_PJOB_FIN && kind != FL_PJOB_EWADD; }
+__device__ __forceinline__ int row_tiles(const fl_pjob& jb) { return flat_kind(jb.kind) ? 1 : (jb.M + TS - 1) / TS; }
 __device__ __forceinline__ int tiles_per_rowtile(const fl_pjob& jb) {
   switch (jb.kind) {
     case FL_PJOB_GEMM: return jb.N / TS;
-    case FL_PJOB_ROWNORM: return TS / 4;
+    case FL_PJOB_ROWNORM:
+    case FL_PJOB_LNBWD:
+    case FL_PJOB_LOSS: return TS / 4;
     case FL_PJOB_SINUSOID: return (TS * (jb.N >> 1) + 255) / 256;
-    default: return (TS * (jb.N >> 2) + 255) / 256;  // GATHER, PSAMPLE: float4 per thread
+    case FL_PJOB_LNCOL: return jb.N / 32;
+    case FL_PJOB_FIN: return 1;
+    case FL_PJOB_EMBBWD: return jb.K[0];
+    case FL_PJOB_SQNORM:
+    case FL_PJOB_ADAM: return FLAT_TILES;
+    default: return (TS * (jb.N >> 2) + 255) / 256;  // GATHER, PSAMPLE, EWADD: float4 per thread
   }
 }
 
@@ -565,11 +995,26 @@ template <bool WT>
 __device__ __forceinline__ void run_tile(const fl_pjob& jb, int rt, int k, const ProgIO& io, float* smem) {
   const int r0 = rt * TS, r1 = r0 + TS < jb.M ? r0 + TS : jb.M;
   switch (jb.kind) {
-    case FL_PJOB_GEMM: gemm_tile<WT>(jb, rt, k, io, smem); break;
+    case FL_PJOB_GEMM:
+      switch (jb.flags & (FL_PG_TA | FL_PG_TW)) {
+        case 0: gemm_tile<WT, false, false>(jb, rt, k, io, smem); break;
+        case FL_PG_TW: gemm_tile<WT, false, true>(jb, rt, k, io, smem); break;
+        case FL_PG_TA | FL_PG_TW: gemm_tile<WT, true, true>(jb, rt, k, io, smem); break;
+        default: break;  // TA alone: rejected by fl_program_job_tiles
+      }
+      break;
     case FL_PJOB_ROWNORM: rownorm_tile<WT>(jb, r0 + 4 * k, io); break;
     case FL_PJOB_SINUSOID: sinusoid_tile<WT>(jb, r0, r1, k, io); break;
     case FL_PJOB_GATHER: gather_tile<WT>(jb, r0, r1, k, io); break;
     case FL_PJOB_PSAMPLE: psample_tile<WT>(jb, r0, r1, k, io); break;
+    case FL_PJOB_LNBWD: lnbwd_tile<WT>(jb, r0 + 4 * k, io); break;
+    case FL_PJOB_LNCOL: lncol_tile<WT>(jb, k, io, smem); break;
+    case FL_PJOB_LOSS: loss_tile<WT>(jb, r0 + 4 * k, io); break;
+    case FL_PJOB_FIN: fin_tile<WT>(jb, io, smem); break;
+    case FL_PJOB_EWADD: ewadd_tile<WT>(jb, r0, r1, k, io); break;
+    case FL_PJOB_EMBBWD: embbwd_tile<WT>(jb, k, io, smem); break;
+    case FL_PJOB_SQNORM: sqnorm_tile<WT>(jb, k, io, smem); break;
+    case FL_PJOB_ADAM: adam_tile(jb, k, io, smem); break;
     default: break;
   }
 }
@@ -659,7 +1104,7 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
         fl_pjob jb;
         load_job(ljb + j * JW, jb);
         const int lt = t - jb.tile_begin;
-        const int nrt = (jb.M + TS - 1) / TS, per = tiles_per_rowtile(jb);
+        const int nrt = row_tiles(jb), per = tiles_per_rowtile(jb);
         int rt, k;
         if (jb.kind == FL_PJOB_GEMM && (per & 7) == 0) {
           // tile lt runs on XCD lt%8 (round-robin block placement): keep a weight column block on one XCD
@@ -678,7 +1123,7 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
       for (int j = job_begin; j < job_end; ++j) {
         fl_pjob jb;
         load_job(ljb + j * JW, jb);
-        const int nrt = (jb.M + TS - 1) / TS, per = tiles_per_rowtile(jb);
+        const int nrt = row_tiles(jb), per = tiles_per_rowtile(jb);
         const int mine = nrt > xcc ? (nrt - xcc + NCTR - 1) / NCTR : 0;
         const int cnt = mine * per;
         // local tile t of this job: first one this block takes is the smallest t >= 0 with (base + t) % nx == slot
@@ -753,18 +1198,27 @@ int fl_program_job_tiles(const void* job) {
   FL_REQUIRE(j.M >= 1 && j.N >= 1 && j.C, "program job: M=%d N=%d C=%llu", j.M, j.N, (unsigned long long)j.C);
   switch (j.kind) {
     case FL_PJOB_GEMM: {
+      const bool ta = (j.flags & FL_PG_TA) != 0, tw = (j.flags & FL_PG_TW) != 0;
       FL_REQUIRE(j.nseg >= 1 && j.nseg <= FL_PROG_MAX_SEG && j.N % TS == 0 && j.ldc % 4 == 0, "program GEMM: nseg=%d N=%d ldc=%d",
                  j.nseg, j.N, j.ldc);
-      for (int s = 0; s < j.nseg; ++s)
-        FL_REQUIRE(j.A[s] && j.W[s] && j.K[s] >= 4 && j.K[s] % 4 == 0 && j.lda[s] % 4 == 0 && j.ldw[s] % 4 == 0 && j.ldw[s] >= j.K[s],
+      FL_REQUIRE(!ta || (tw && j.M % TS == 0), "program GEMM: FL_PG_TA needs FL_PG_TW and M %% 32 == 0 (M=%d)", j.M);
+      for (int s = 0; s < j.nseg; ++s) {
+        FL_REQUIRE(j.A[s] && j.W[s] && j.K[s] >= 1 && j.lda[s] % 4 == 0 && j.ldw[s] % 4 == 0,
                    "program GEMM segment %d: K=%d lda=%d ldw=%d", s, j.K[s], j.lda[s], j.ldw[s]);
-      for (int s = 0; s < j.nseg; ++s)  // operands are addressed with 32-bit element offsets and 24-bit multiplies
-        FL_REQUIRE(j.M < (1 << 24) && j.N < (1 << 24) && j.lda[s] >= 0 && j.lda[s] < (1 << 24) && j.ldw[s] < (1 << 24) &&
-                       (long long)j.M * j.lda[s] < (1ll << 30) && (long long)j.N * j.ldw[s] < (1ll << 30),
+        FL_REQUIRE(ta || (j.K[s] >= 4 && j.K[s] % 4 == 0), "program GEMM segment %d: K=%d", s, j.K[s]);
+        FL_REQUIRE(tw ? j.ldw[s] >= j.N : j.ldw[s] >= j.K[s], "program GEMM segment %d: ldw=%d", s, j.ldw[s]);
+        FL_REQUIRE(!ta || j.lda[s] >= j.M, "program GEMM segment %d: lda=%d", s, j.lda[s]);
+        // operands are addressed with 32-bit element offsets and 24-bit multiplies
+        const long long arows = ta ? j.K[s] : j.M, wrows = tw ? j.K[s] : j.N;
+        FL_REQUIRE(arows < (1 << 24) && wrows < (1 << 24) && j.lda[s] >= 0 && j.lda[s] < (1 << 24) && j.ldw[s] < (1 << 24) &&
+                       arows * j.lda[s] < (1ll << 30) && wrows * j.ldw[s] < (1ll << 30),
                    "program GEMM segment %d: operand too large for 32-bit offsets", s);
+      }
       FL_REQUIRE(!j.R || j.ldr % 4 == 0, "program GEMM: ldr=%d", j.ldr);
       FL_REQUIRE(!j.mask || (j.mask_group >= 4 && j.mask_group % 4 == 0 && j.N % j.mask_group == 0), "program GEMM: mask_group=%d",
                  j.mask_group);
+      FL_REQUIRE(!(j.flags & FL_PG_COLSUM) || (ta && j.aux[0]), "program GEMM: FL_PG_COLSUM needs FL_PG_TA and aux[0]");
+      FL_REQUIRE(!(j.flags & FL_PG_ACTBWD) || (j.aux[1] && j.ld2 % 4 == 0), "program GEMM: FL_PG_ACTBWD needs aux[1] (ld2=%d)", j.ld2);
       return ((j.M + TS - 1) / TS) * (j.N / TS);
     }
     case FL_PJOB_ROWNORM:
@@ -785,6 +1239,38 @@ int fl_program_job_tiles(const void* job) {
                  "program PSAMPLE: needs x, eps, alpha/alpha_bar/beta tables, t and noise or a Philox offset (M*N %% 4 == 0)");
       FL_REQUIRE(j.N % 4 == 0, "program PSAMPLE: N %% 4");
       return ((j.M + TS - 1) / TS) * ((TS * (j.N / 4) + 255) / 256);
+    case FL_PJOB_LNBWD:
+      FL_REQUIRE(j.A[0] && j.A[1] && j.W[0] && j.bias[0] && j.N % 256 == 0 && j.N <= 1024 && j.lda[0] % 4 == 0 &&
+                     j.lda[1] % 4 == 0 && j.ldc % 4 == 0 && (!j.R || j.ldr % 4 == 0),
+                 "program LNBWD: N=%d lda=%d,%d ldc=%d", j.N, j.lda[0], j.lda[1], j.ldc);
+      return ((j.M + TS - 1) / TS) * (TS / 4);
+    case FL_PJOB_LNCOL:
+      FL_REQUIRE(j.A[0] && j.A[1] && j.aux[0] && j.aux[1] && j.N % 32 == 0, "program LNCOL: N=%d", j.N);
+      return j.N / 32;
+    case FL_PJOB_LOSS:
+      FL_REQUIRE(j.A[0] && j.A[1] && j.aux[0] && j.N % 256 == 0 && j.N <= 1024 && j.lda[0] % 4 == 0 && j.lda[1] % 4 == 0 &&
+                     j.ldc % 4 == 0 && (!j.A[2] || (j.aux[1] && j.lda[2] % 4 == 0)),
+                 "program LOSS: N=%d", j.N);
+      return ((j.M + TS - 1) / TS) * (TS / 4);
+    case FL_PJOB_FIN:
+      FL_REQUIRE(j.A[0] && (!j.A[1] || (j.aux[0] && j.gate)), "program FIN: the gate gradient needs aux[0] and gate");
+      return 1;
+    case FL_PJOB_EWADD:
+      FL_REQUIRE(j.A[0] && j.A[1] && j.N % 4 == 0 && j.lda[0] % 4 == 0 && j.lda[1] % 4 == 0 && j.lda[2] % 4 == 0 && j.ldc % 4 == 0,
+                 "program EWADD: N=%d", j.N);
+      return ((j.M + TS - 1) / TS) * ((TS * (j.N / 4) + 255) / 256);
+    case FL_PJOB_EMBBWD:
+      FL_REQUIRE(j.A[0] && j.W[0] && j.K[0] >= 1 && j.N % 4 == 0 && j.N <= 4096 && j.lda[0] % 4 == 0 && j.ldc % 4 == 0,
+                 "program EMBBWD: rows=%d N=%d", j.K[0], j.N);
+      return j.K[0];
+    case FL_PJOB_SQNORM:
+      FL_REQUIRE(j.A[0] && j.K[0] >= 4 && j.K[0] % 4 == 0 && j.K[0] < (1 << 30), "program SQNORM: n=%d", j.K[0]);
+      return FLAT_TILES;
+    case FL_PJOB_ADAM:
+      FL_REQUIRE(j.A[0] && j.W[0] && j.W[1] && j.W[2] && j.aux[0] && j.aux[1] && j.K[0] >= 4 && j.K[0] % 4 == 0 &&
+                     j.K[0] < (1 << 30),
+                 "program ADAM: needs g, partials, lr, step, m, v (n=%d)", j.K[0]);
+      return FLAT_TILES;
     default:
       fl::set_error("program job: unknown kind %d", j.kind);
       return FL_ERR_BAD_ARG;

@@ -15,7 +15,8 @@ from . import lib, ops
 
 import os
 
-GEMM, ROWNORM, SINUSOID, GATHER, PSAMPLE = 0, 1, 2, 3, 4
+GEMM, ROWNORM, SINUSOID, GATHER, PSAMPLE, LNBWD, LNCOL, LOSS, FIN, EWADD, EMBBWD, SQNORM, ADAM = range(13)
+PG_TA, PG_TW, PG_COLSUM, PG_ACTBWD, PG_DECOUPLED = 1, 2, 4, 8, 16
 LOCAL_DEFAULT = os.environ.get("FL_PROG_LOCAL", "0") == "1"  # opt-in XCD-local execution (same speed, see program.hip)
 MAX_IO = 16
 
@@ -23,7 +24,8 @@ JOB_DTYPE = np.dtype([
     ("A", "<u8", 3), ("W", "<u8", 3), ("bias", "<u8", 3), ("R", "<u8"), ("C", "<u8"), ("mask", "<u8"), ("gate", "<u8"),
     ("aux", "<u8", 4), ("kind", "<i4"), ("M", "<i4"), ("N", "<i4"), ("nseg", "<i4"), ("K", "<i4", 3), ("lda", "<i4", 3),
     ("ldw", "<i4", 3), ("ldr", "<i4"), ("ldc", "<i4"), ("act", "<i4"), ("mask_group", "<i4"), ("tile_begin", "<i4"),
-    ("ntiles", "<i4"), ("bias_scale", "<f4", 3), ("eps", "<f4"), ("eps2", "<f4"), ("bias_row_stride", "<i4"), ("pad_", "<i4")])
+    ("ntiles", "<i4"), ("bias_scale", "<f4", 3), ("eps", "<f4"), ("eps2", "<f4"), ("bias_row_stride", "<i4"), ("flags", "<i4"),
+    ("alpha", "<f4"), ("ld2", "<i4"), ("pad_", "<i4", 2)])
 POST_DTYPE = np.dtype([("ptr64", "<u8", 2), ("delta64", "<i8", 2), ("ptr32", "<u8"), ("delta32", "<i4"), ("pad_", "<i4")])
 PHASE_DTYPE = np.dtype([("job_begin", "<i4"), ("job_end", "<i4"), ("ntiles", "<i4"), ("flags", "<i4")])
 PHASE_ACQUIRE = 1
@@ -82,10 +84,18 @@ class ProgramBuilder:
                                  [self._key(w) for w in writes if w is not None]))
 
     def gemm(self, M, N, segs, C, ldc, biases=(), act=ops.ACT_NONE, R=None, ldr=0, mask=None, mask_group=0, gate=None,
-             bias_row_index=None, bias_row_stride=0):
+             bias_row_index=None, bias_row_stride=0, ta=False, tw=False, colsum=None, colsum_alpha=1.0, actbwd=None,
+             ld_actbwd=0, pre_out=None):
         """C[M,N] = epi(sum_s A_s W_s^T). segs: [(A, lda, K, W, ldw)]; biases: [(bias, scale)]; with bias_row_index (a
-        device int64) biases[0] is row *index of a table with row stride bias_row_stride."""
+        device int64) biases[0] is row *index of a table with row stride bias_row_stride.
+        ta / tw: operand stored with the contraction index as its row (A[k][m], W[k][n]); colsum (needs ta): vector that
+        receives colsum_alpha * (1 + sigmoid(gate)) * sum_k A[k][m]; actbwd: tensor P, the result is multiplied by
+        act'(P[row][col]) instead of being activated; pre_out: also store the pre-activation value there."""
         j = np.zeros((), JOB_DTYPE)
+        j["flags"] = (PG_TA if ta else 0) | (PG_TW if tw else 0) | (PG_COLSUM if colsum is not None else 0) | \
+            (PG_ACTBWD if actbwd is not None else 0)
+        j["aux"][0], j["alpha"], j["aux"][1], j["ld2"], j["aux"][3] = _ptr(colsum), colsum_alpha, _ptr(actbwd), ld_actbwd, _ptr(pre_out)
+        self._hold(colsum, actbwd, pre_out)
         j["kind"], j["M"], j["N"], j["nseg"] = GEMM, M, N, len(segs)
         for s, (A, lda, K, W, ldw) in enumerate(segs):
             j["A"][s], j["lda"][s], j["K"][s], j["W"][s], j["ldw"][s] = _ptr(A), lda, K, _ptr(W), ldw
@@ -98,7 +108,77 @@ class ProgramBuilder:
         j["mask"], j["mask_group"], j["gate"] = _ptr(mask), mask_group, _ptr(gate)
         j["aux"][2], j["bias_row_stride"] = _ptr(bias_row_index), bias_row_stride
         self._hold(C, R, mask, gate, bias_row_index)
-        self._add(j, [a[0] for a in segs] + [R, mask, bias_row_index], [C])
+        self._add(j, [a[0] for a in segs] + [a[3] for a in segs if ta or tw] + [R, mask, bias_row_index, actbwd],
+                  [C, colsum, pre_out])
+
+    def lnbwd(self, M, D, x, ldx, dy, lddy, w, b, eps, dx, ld, act=ops.ACT_NONE, mask=None, R=None, ldr=0, gl=None, stats=None):
+        """row LayerNorm backward: dx = LN'(dy * act'(u) * mask) + R; gl (optional) receives the gradient w.r.t. the LN
+        output, stats [M,2] the recomputed (mean, rstd)."""
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = LNBWD, M, D
+        j["A"][0], j["lda"][0], j["A"][1], j["lda"][1] = _ptr(x), ldx, _ptr(dy), lddy
+        j["W"][0], j["bias"][0], j["eps"], j["act"], j["mask"] = _ptr(w), _ptr(b), eps, act, _ptr(mask)
+        j["R"], j["ldr"], j["C"], j["ldc"], j["aux"][0], j["aux"][1] = _ptr(R), ldr, _ptr(dx), ld, _ptr(gl), _ptr(stats)
+        self._hold(x, dy, w, b, mask, R, dx, gl, stats)
+        self._add(j, [x, dy, mask, R], [dx, gl, stats])
+
+    def lncol(self, M, D, gl, ldg, x, ldx, stats, dw, db):
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = LNCOL, M, D
+        j["A"][0], j["lda"][0], j["A"][1], j["lda"][1], j["aux"][1] = _ptr(gl), ldg, _ptr(x), ldx, _ptr(stats)
+        j["C"], j["aux"][0] = _ptr(dw), _ptr(db)
+        self._hold(gl, x, stats, dw, db)
+        self._add(j, [gl, x, stats], [dw, db])
+
+    def loss(self, M, D, pred, target, dout, norms, alpha, r=None, rowdot=None):
+        """euclidean_distance_loss rows (v2:293-302): norms[m], dout = alpha * d/norm, rowdot[m] = <dout[m], r[m]>."""
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"], j["alpha"] = LOSS, M, D, alpha
+        j["A"][0], j["A"][1], j["A"][2] = _ptr(pred), _ptr(target), _ptr(r)
+        j["lda"][0] = j["lda"][1] = j["lda"][2] = D
+        j["C"], j["ldc"], j["aux"][0], j["aux"][1] = _ptr(dout), D, _ptr(norms), _ptr(rowdot)
+        self._hold(pred, target, r, dout, norms, rowdot)
+        self._add(j, [pred, target, r], [dout, norms, rowdot])
+
+    def fin(self, M, norms, loss, rowdot=None, gate=None, ggate=None):
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = FIN, M, 1
+        j["A"][0], j["A"][1], j["C"], j["aux"][0], j["gate"] = _ptr(norms), _ptr(rowdot), _ptr(loss), _ptr(ggate), _ptr(gate)
+        self._hold(norms, rowdot, loss, gate, ggate)
+        self._add(j, [norms, rowdot], [loss, ggate])
+
+    def ewadd(self, M, N, a, b, C, c=None):
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = EWADD, M, N
+        j["A"][0], j["A"][1], j["A"][2], j["C"], j["ldc"] = _ptr(a), _ptr(b), _ptr(c), _ptr(C), N
+        j["lda"][0] = j["lda"][1] = j["lda"][2] = N
+        self._hold(a, b, c, C)
+        self._add(j, [a, b, c], [C])
+
+    def embbwd(self, B, D, rows, dout, idx, dtable):
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = EMBBWD, B, D
+        j["K"][0], j["A"][0], j["lda"][0], j["W"][0], j["C"], j["ldc"] = rows, _ptr(dout), D, _ptr(idx), _ptr(dtable), D
+        self._hold(dout, idx, dtable)
+        self._add(j, [dout, idx], [dtable])
+
+    def sqnorm(self, n, g, partials):
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = SQNORM, 1, 1
+        j["K"][0], j["A"][0], j["C"] = n, _ptr(g), _ptr(partials)
+        self._hold(g, partials)
+        self._add(j, [g], [partials])
+
+    def adam(self, n, p, g, m, v, partials, lr, step, b1, b2, eps, wd, decoupled, gscale=1.0, max_norm=None, coef=None,
+             gnorm=None):
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = ADAM, 1, 1
+        j["K"][0], j["A"][0], j["C"], j["aux"][0], j["aux"][1] = n, _ptr(g), _ptr(p), _ptr(m), _ptr(v)
+        j["W"][0], j["W"][1], j["W"][2], j["aux"][2], j["aux"][3] = _ptr(partials), _ptr(lr), _ptr(step), _ptr(coef), _ptr(gnorm)
+        j["bias_scale"][0], j["bias_scale"][1], j["bias_scale"][2] = b1, b2, (max_norm if max_norm is not None else 0.0)
+        j["eps"], j["eps2"], j["alpha"], j["flags"] = eps, wd, gscale, (PG_DECOUPLED if decoupled else 0)
+        self._hold(p, g, m, v, partials, lr, step, coef, gnorm)
+        self._add(j, [g, p, m, v, partials, lr, step], [p, m, v, coef, gnorm])
 
     def rownorm(self, M, D, x, ldx, w, b, eps, C, ldc, act=ops.ACT_NONE, mask=None, R=None, ldr=0, w2=None, b2=None,
                 eps2=1e-5, C2=None, gate=None, gx=None, ldgx=0):

@@ -148,8 +148,14 @@ def shard_seed(base, rank):
 class DDPMTrainer:
     """Latent-DDPM training step (configs 3/4 of BASELINE.json)."""
 
-    def __init__(self, autoencoder, unet, lr=1e-3, n_steps=1000, process_group=None, world_size=1):
+    def __init__(self, autoencoder, unet, lr=1e-3, n_steps=1000, process_group=None, world_size=1, persistent=None):
+        """persistent: run the denoiser forward/backward and clip+AdamW as persistent phase programs (program_train.py:
+        2 launches instead of ~240; they need the whole device, so nothing else may run next to them). None = the
+        FL_TRAIN_PROGRAM environment variable (default on)."""
         from .modules import ConditionalDenoiseDiffusion
+        import os
+        self.persistent = (os.environ.get("FL_TRAIN_PROGRAM", "1") == "1") if persistent is None else bool(persistent)
+        self._tprog, self._oprog = {}, None
         self.ae, self.unet = autoencoder, unet
         self.ae.eval()
         dev = next(unet.parameters()).device
@@ -185,6 +191,10 @@ class DDPMTrainer:
         if self.unet.training and block_masks is None and self.unet.dropout_rate > 0:
             block_masks, head_masks = self.unet.dropout_masks(B, z.device)
         xt = ops.q_sample(z, eps, t, d.alpha_bar)
+        if self.persistent and labels is not None and t.numel() == B and self._program_shapes_ok():
+            prog = self._train_program(B, block_masks is not None)
+            self.eps_theta = prog.run(xt, t, labels, eps, block_masks, head_masks)   # loss and every gradient included
+            return
         eps_theta, S = engine.unet_forward(self.unet, xt, t, labels, block_masks, head_masks, save=True)
         loss, norms = ops.euclid_loss_fwd(eps_theta, eps)
         dout = ops.euclid_loss_bwd(eps_theta, eps, norms)
@@ -192,11 +202,37 @@ class DDPMTrainer:
         ops.axpby(1.0, loss, out=self.loss)
         self.eps_theta = eps_theta
 
+    def _program_shapes_ok(self):
+        un = self.unet
+        dims = [blk[0].weight.shape[0] for blk, _, _ in un.layers] + [un.final_time_proj.weight.shape[0]]
+        return all(dd % 256 == 0 and dd <= 1024 for dd in dims) and un.latent_dim % 256 == 0 and un.latent_dim <= 1024 and \
+            un.time_emb_dim % 32 == 0 and un.time_emb.lin1.weight.shape[0] % 32 == 0 and \
+            un.class_emb.lin1.weight.shape[0] % 32 == 0
+
+    def _train_program(self, B, masks):
+        from .program_train import DenoiserTrainProgram
+        prog = self._tprog.get((B, masks))
+        if prog is not None and prog.key != tuple(p.data_ptr() for p in self.unet.parameters()) + tuple(
+                g.data_ptr() for g in self.fp.gviews.values()):
+            prog = None  # a parameter was re-allocated: rebuild
+        if prog is None:
+            prog = DenoiserTrainProgram(self.unet, self.fp.gviews, B, self.dev, masks=masks, loss_out=self.loss)
+            self._tprog[(B, masks)] = prog
+        return prog
+
     def allreduce(self):
         allreduce_grads(self.fp, self.world, self.pg)
 
     @torch.no_grad()
     def update(self):
+        if self.persistent:
+            from .program_train import OptimizerProgram
+            o, n, gs = self.opt, self.fp.n_active, 1.0 / self.world
+            key = (n, gs, tuple(o.betas), o.eps, o.wd, o.decoupled, o.max_norm, self.fp.flat.data_ptr(), self.fp.grad.data_ptr())
+            if self._oprog is None or self._oprog.key != key:
+                self._oprog = OptimizerProgram(o, n, gs)
+            self._oprog.run()
+            return
         self.opt.step(gscale=1.0 / self.world)
 
     @torch.no_grad()
@@ -239,6 +275,7 @@ class DDPMTrainer:
     def capture_pipelined(self, data, labels):
         dev = self.dev
         self.static_data, self.static_labels = data, labels
+        self.persistent = False  # two streams share the device here: a persistent program cannot run next to stream E
         for _ in range(2):
             self.step(data, labels)
         # stream priorities (experiment knob, default none): FL_PIPE_PRIO="e,u", -1 = high

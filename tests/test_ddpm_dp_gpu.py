@@ -47,7 +47,8 @@ def _worker(rank, world, port, ret, pipelined):
     un = M.ConditionalUNet()
     un.load_state_dict(pinit.procedural_state_dict(un.state_dict(), 44))
     ae, un = ae.to(dev).eval(), un.to(dev).eval()  # eval: dropout off, explicit noise -> comparable with the oracle
-    tr = steps.DDPMTrainer(ae, un, lr=1e-3, process_group=dist.group.WORLD, world_size=world)
+    # both ranks share ONE GPU here: the persistent programs need a whole device each, so this rehearsal runs the multi-kernel path
+    tr = steps.DDPMTrainer(ae, un, lr=1e-3, process_group=dist.group.WORLD, world_size=world, persistent=False)
     batches = _inputs()
     per = batches[0]["data"].shape[0] // world
     sl = slice(rank * per, (rank + 1) * per)

@@ -17,7 +17,7 @@ def jobs_of(prog):
 
 def test_struct_packing_matches_library():
     L = lib.load()
-    assert P.JOB_DTYPE.itemsize == L.fl_program_job_bytes() == 240
+    assert P.JOB_DTYPE.itemsize == L.fl_program_job_bytes() == 256
     assert P.PHASE_DTYPE.itemsize == L.fl_program_phase_bytes() == 16
     assert L.fl_program_sync_bytes() >= 4 * (P.SYNC_ABORT_WORD + 1)
     assert P.POST_DTYPE.itemsize == 48
