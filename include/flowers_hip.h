@@ -399,7 +399,10 @@ int fl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float
  *                    aux[3] != 0: the pre-activation value is stored there too (row stride ldc).
  *   FL_PJOB_LNBWD    row LayerNorm backward: x = A[0], dy = A[1]; u = mask*(xhat*W[0]+bias[0]); gl = dy*act'(u)*mask;
  *                    C = rstd*(gl*w - mean(gl*w) - xhat*mean(gl*w*xhat)) + R; aux[0] = gl (optional), aux[1] = [M][2]
- *                    (mean, rstd) recomputed from x exactly as FL_PJOB_ROWNORM computes them.
+ *                    (mean, rstd) recomputed from x exactly as FL_PJOB_ROWNORM computes them. Two-stage form (A[2] != 0,
+ *                    the backward of ROWNORM's second LayerNorm chained into its first): stage 1 = plain LN backward with
+ *                    W[1], bias[1], eps2 on x = A[0], dy = A[1], + R -> aux[2] (stats -> aux[3]); stage 2 = the above on
+ *                    x = A[2] with that result as dy (no R).
  *   FL_PJOB_LNCOL    C[n] = sum_m gl[m][n]*(x[m][n]-mean_m)*rstd_m, aux[0][n] = sum_m gl[m][n]; gl = A[0], x = A[1],
  *                    stats = aux[1]  (LayerNorm weight / bias gradients, 32 columns per tile).
  *   FL_PJOB_LOSS     rows of euclidean_distance_loss (v2:293-302) and its gradient: d = A[0]-A[1]; aux[0][m] =

@@ -196,7 +196,7 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
   const int am0 = rt * TS + tc4, wn0 = ct * TS + tc4;  // ... or these columns of rows k (transposed operands)
   const int Mm1 = jb.M - 1;
 
-  // global -> registers for chunk c (clamped: a surplus stage re-reads the last chunk and is never consumed);
+  // global -> registers for chunk c;
   // okvar: this thread's 16-byte column lies inside the chunk's valid k range; kvvar: valid k rows of the chunk
 #define FL_ISSUE(RS, cidx, okvar, kvvar)                                                           \
   do {                                                                                             \
@@ -313,21 +313,23 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
   if (jb.R) e_r = ld4g(rp(jb.R, io) + (long long)grc * jb.ldr + gc);
   if (actbwd) e_p = ld4g(rp(jb.aux[1], io) + (long long)grc * jb.ld2 + gc);
   Stage R0, R1;
-  bool ok0, ok1;
-  int kv0, kv1;
+  bool ok0 = false, ok1 = false;
+  int kv0 = 0, kv1 = 0;
   FL_STAMP(7);
+  // (chunks past the last one are not requested: a one-chunk tile - every weight-gradient tile at batch 256 - would
+  // otherwise fetch its operands four times over)
   FL_ISSUE(R0, 0, ok0, kv0);
-  FL_ISSUE(R1, 1, ok1, kv1);
+  if (nC > 1) FL_ISSUE(R1, 1, ok1, kv1);
   FL_STAMP(8);
   for (int c = 0; c < nC; c += 2) {
     FL_PARK(R0, ok0, kv0, 0);
-    FL_ISSUE(R0, c + 2, ok0, kv0);
+    if (c + 2 < nC) FL_ISSUE(R0, c + 2, ok0, kv0);
     __syncthreads();
     FL_CONTRACT(0);
     FL_COLSUM(0);
     const bool more = c + 1 < nC;  // block-uniform
     if (more) FL_PARK(R1, ok1, kv1, 1);
-    FL_ISSUE(R1, c + 3, ok1, kv1);
+    if (c + 3 < nC) FL_ISSUE(R1, c + 3, ok1, kv1);
     __syncthreads();
     if (more) {
       FL_CONTRACT(1);
@@ -567,7 +569,63 @@ __device__ __forceinline__ void psample_tile(const fl_pjob& jb, int r0, int r1, 
 
 // ---------------------------------------------------------------------------------------------- training kinds
 // Row LayerNorm backward (same arithmetic as layernorm_bwd_dx_kernel in norm.hip); mean / rstd are recomputed from the
-// saved input exactly as rownorm_tile computed them in the forward. One wave per row.
+// saved input exactly as rownorm_tile computed them in the forward. One wave per row; v = x row, g = dy row on entry,
+// g = dx (without the residual) on return.
+template <bool WT>
+__device__ __forceinline__ void ln_bwd_row(float4 (&v)[4], float4 (&g)[4], const float* w1, const float* b1, const float* mk,
+                                           int act, float eps, int D, int nv, int lane, float* glo, float& m_out, float& r_out) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float m = fl::wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      const float a = v[i].x - m, b = v[i].y - m, c = v[i].z - m, d = v[i].w - m;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float r = 1.0f / sqrtf(fl::wave_sum(q) / D + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      const int o = (i * 64 + lane) * 4;
+      const float4 ww = ld4g(w1 + o), bb = ld4g(b1 + o);
+      float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (mk) k = ld4g(mk + o);
+      float4 xh, gl;
+      xh.x = (v[i].x - m) * r; xh.y = (v[i].y - m) * r; xh.z = (v[i].z - m) * r; xh.w = (v[i].w - m) * r;
+      gl.x = g[i].x * act_grad(k.x * (xh.x * ww.x + bb.x), act) * k.x;
+      gl.y = g[i].y * act_grad(k.y * (xh.y * ww.y + bb.y), act) * k.y;
+      gl.z = g[i].z * act_grad(k.z * (xh.z * ww.z + bb.z), act) * k.z;
+      gl.w = g[i].w * act_grad(k.w * (xh.w * ww.w + bb.w), act) * k.w;
+      if (glo) st4g<WT>(glo + o, gl);
+      g[i].x = gl.x * ww.x; g[i].y = gl.y * ww.y; g[i].z = gl.z * ww.z; g[i].w = gl.w * ww.w;  // d xhat
+      v[i] = xh;
+      s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      s2 += (g[i].x * xh.x + g[i].y * xh.y) + (g[i].z * xh.z + g[i].w * xh.w);
+    }
+  }
+  const float t1 = fl::wave_sum(s1) / D, t2 = fl::wave_sum(s2) / D;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < nv) {
+      g[i].x = r * (g[i].x - t1 - v[i].x * t2);
+      g[i].y = r * (g[i].y - t1 - v[i].y * t2);
+      g[i].z = r * (g[i].z - t1 - v[i].z * t2);
+      g[i].w = r * (g[i].w - t1 - v[i].w * t2);
+    }
+  }
+  m_out = m;
+  r_out = r;
+}
+
+// FL_PJOB_LNBWD. With A[2] (a second, inner LayerNorm whose OUTPUT + R-path fed the first one's input, v2:514-516 followed
+// by the layer norm of v2:549): stage 1 is the plain (no mask / activation) backward of LN(W[1], bias[1]) on x = A[0] plus
+// the residual R, stored to aux[2]; stage 2 continues in registers with x = A[2], W[0], bias[0], mask, act.
 template <bool WT>
 __device__ __forceinline__ void lnbwd_tile(const fl_pjob& jb, int row4, const ProgIO& io) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -578,61 +636,47 @@ __device__ __forceinline__ void lnbwd_tile(const fl_pjob& jb, int row4, const Pr
   const float* dy = rp(jb.A[1], io) + (long long)row * jb.lda[1];
   const float* mk = jb.mask ? rp(jb.mask, io) + (long long)row * D : nullptr;
   const float* R = jb.R ? rp(jb.R, io) + (long long)row * jb.ldr : nullptr;
-  const float* w1 = rp(jb.W[0], io);
-  const float* b1 = rp(jb.bias[0], io);
-  float4 v[4], g[4];
-  float s = 0.f;
+  const bool two = jb.A[2] != 0;
+  float4 v[4], g[4], v2[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (i < nv) {
       v[i] = ld4g(x + (i * 64 + lane) * 4);
       g[i] = ld4g(dy + (i * 64 + lane) * 4);
-      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      if (two) v2[i] = ld4g(rp(jb.A[2], io) + (long long)row * jb.lda[2] + (i * 64 + lane) * 4);
     }
   }
-  const float m = fl::wave_sum(s) / D;
-  float q = 0.f;
+  float m, r;
+  if (two) {
+    ln_bwd_row<WT>(v, g, rp(jb.W[1], io), rp(jb.bias[1], io), nullptr, FL_ACT_NONE, jb.eps2, D, nv, lane, nullptr, m, r);
+    float* mid = wp(jb.aux[2], io) + (long long)row * jb.ldc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < nv) {
-      const float a = v[i].x - m, b = v[i].y - m, c = v[i].z - m, d = v[i].w - m;
-      q += (a * a + b * b) + (c * c + d * d);
+    for (int i = 0; i < 4; ++i) {
+      if (i < nv) {
+        const int o = (i * 64 + lane) * 4;
+        if (R) {
+          const float4 k = ld4g(R + o);
+          g[i].x += k.x; g[i].y += k.y; g[i].z += k.z; g[i].w += k.w;
+        }
+        st4g<WT>(mid + o, g[i]);
+        v[i] = v2[i];
+      }
     }
+    if (jb.aux[3] && lane == 0) {
+      float* st = wp(jb.aux[3], io) + 2 * (long long)row;
+      st1g<WT>(st, m);
+      st1g<WT>(st + 1, r);
+    }
+    R = nullptr;
   }
-  const float r = 1.0f / sqrtf(fl::wave_sum(q) / D + jb.eps);
-  float s1 = 0.f, s2 = 0.f;
   float* glo = jb.aux[0] ? wp(jb.aux[0], io) + (long long)row * jb.ldc : nullptr;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < nv) {
-      const int o = (i * 64 + lane) * 4;
-      const float4 ww = ld4g(w1 + o), bb = ld4g(b1 + o);
-      float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (mk) k = ld4g(mk + o);
-      float4 xh, gl;
-      xh.x = (v[i].x - m) * r; xh.y = (v[i].y - m) * r; xh.z = (v[i].z - m) * r; xh.w = (v[i].w - m) * r;
-      gl.x = g[i].x * act_grad(k.x * (xh.x * ww.x + bb.x), jb.act) * k.x;
-      gl.y = g[i].y * act_grad(k.y * (xh.y * ww.y + bb.y), jb.act) * k.y;
-      gl.z = g[i].z * act_grad(k.z * (xh.z * ww.z + bb.z), jb.act) * k.z;
-      gl.w = g[i].w * act_grad(k.w * (xh.w * ww.w + bb.w), jb.act) * k.w;
-      if (glo) st4g<WT>(glo + o, gl);
-      g[i].x = gl.x * ww.x; g[i].y = gl.y * ww.y; g[i].z = gl.z * ww.z; g[i].w = gl.w * ww.w;  // d xhat
-      v[i] = xh;
-      s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
-      s2 += (g[i].x * xh.x + g[i].y * xh.y) + (g[i].z * xh.z + g[i].w * xh.w);
-    }
-  }
-  const float t1 = fl::wave_sum(s1) / D, t2 = fl::wave_sum(s2) / D;
+  ln_bwd_row<WT>(v, g, rp(jb.W[0], io), rp(jb.bias[0], io), mk, jb.act, jb.eps, D, nv, lane, glo, m, r);
   float* dx = wp(jb.C, io) + (long long)row * jb.ldc;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (i < nv) {
       const int o = (i * 64 + lane) * 4;
-      float4 y;
-      y.x = r * (g[i].x - t1 - v[i].x * t2);
-      y.y = r * (g[i].y - t1 - v[i].y * t2);
-      y.z = r * (g[i].z - t1 - v[i].z * t2);
-      y.w = r * (g[i].w - t1 - v[i].w * t2);
+      float4 y = g[i];
       if (R) {
         const float4 k = ld4g(R + o);
         y.x += k.x; y.y += k.y; y.z += k.z; y.w += k.w;
@@ -647,37 +691,40 @@ __device__ __forceinline__ void lnbwd_tile(const fl_pjob& jb, int row4, const Pr
   }
 }
 
-// LayerNorm weight / bias gradients: 32 columns per tile, 8 row groups, LDS tree. The row statistics are staged in LDS
-// (coherent loads, one round trip) 1024 rows at a time.
+// LayerNorm weight / bias gradients: 32 columns per tile. A lane owns 4 columns of every 32nd row (a wave's load covers
+// 8 rows x 128 B), the 32 row groups meet in an LDS tree. The row statistics are staged in LDS (coherent loads).
 template <bool WT>
 __device__ __forceinline__ void lncol_tile(const fl_pjob& jb, int k, const ProgIO& io, float* smem) {
-  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const float* gl = rp(jb.A[0], io) + k * 32 + c;
-  const float* x = rp(jb.A[1], io) + k * 32 + c;
+  const int c4 = (threadIdx.x & 7) * 4, rg = threadIdx.x >> 3;
+  const float* gl = rp(jb.A[0], io) + k * 32 + c4;
+  const float* x = rp(jb.A[1], io) + k * 32 + c4;
   const float* st = rp(jb.aux[1], io);
-  float aw = 0.f, ab = 0.f;
+  float4 aw = make_float4(0.f, 0.f, 0.f, 0.f), ab = aw;
   for (int base = 0; base < jb.M; base += 1024) {
     const int rows = jb.M - base < 1024 ? jb.M - base : 1024;
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * rows; i += 256) *(lf1_t*)(smem + i) = ld1c(st + 2 * base + i);
     __syncthreads();
 #pragma unroll 8
-    for (int m = rg; m < rows; m += 8) {
-      const float gv = ld1g(gl + (long long)(base + m) * jb.lda[0]), xv = ld1g(x + (long long)(base + m) * jb.lda[1]);
+    for (int m = rg; m < rows; m += 32) {
+      const float4 gv = ld4g(gl + (long long)(base + m) * jb.lda[0]), xv = ld4g(x + (long long)(base + m) * jb.lda[1]);
       const float mu = *(const lf1_t*)(smem + 2 * m), rs = *(const lf1_t*)(smem + 2 * m + 1);
-      aw += gv * ((xv - mu) * rs);
-      ab += gv;
+      aw.x += gv.x * ((xv.x - mu) * rs); aw.y += gv.y * ((xv.y - mu) * rs);
+      aw.z += gv.z * ((xv.z - mu) * rs); aw.w += gv.w * ((xv.w - mu) * rs);
+      ab.x += gv.x; ab.y += gv.y; ab.z += gv.z; ab.w += gv.w;
     }
   }
   __syncthreads();
-  *(lf1_t*)(smem + threadIdx.x) = aw;
-  *(lf1_t*)(smem + 256 + threadIdx.x) = ab;
+  // [which][row group 32][32 columns]
+  f32x4v t0 = {aw.x, aw.y, aw.z, aw.w}, t1 = {ab.x, ab.y, ab.z, ab.w};
+  *(lf4_t*)(smem + rg * 32 + c4) = t0;
+  *(lf4_t*)(smem + 1024 + rg * 32 + c4) = t1;
   __syncthreads();
   if (threadIdx.x < 64) {
-    const int which = threadIdx.x >> 5;
+    const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
     float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) t += *(const lf1_t*)(smem + which * 256 + g * 32 + c);
+    for (int g = 0; g < 32; ++g) t += *(const lf1_t*)(smem + which * 1024 + g * 32 + c);
     st1g<WT>(wp(which ? jb.aux[0] : jb.C, io) + k * 32 + c, t);
   }
   __syncthreads();
@@ -772,30 +819,29 @@ __device__ __forceinline__ void ewadd_tile(const fl_pjob& jb, int r0, int r1, in
   st4g<WT>(wp(jb.C, io) + (long long)b * jb.ldc + d, v);
 }
 
-// deterministic embedding gradient: tile = table row r; the batch's indices are walked from LDS, rows that match are added
+// deterministic embedding gradient: tile = table row r; every wave ballots the batch's indices against r (64 at a time) and
+// adds the matching rows in batch order
 template <bool WT>
 __device__ __forceinline__ void embbwd_tile(const fl_pjob& jb, int r, const ProgIO& io, float* smem) {
   const long long* idx = reinterpret_cast<const long long*>(rp(jb.W[0], io));
   const float* src = rp(jb.A[0], io);
   const int D = jb.N, nv = (D + 1023) >> 10;  // float4 per thread (D <= 4096)
+  const int lane = threadIdx.x & 63;
   float4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __attribute__((address_space(3))) int* li = (__attribute__((address_space(3))) int*)smem;
-  for (int b0 = 0; b0 < jb.M; b0 += 256) {
-    __syncthreads();
-    li[threadIdx.x] = b0 + (int)threadIdx.x < jb.M ? (int)ldi64g(idx + b0 + threadIdx.x) : -1;
-    __syncthreads();
-    const int nb = jb.M - b0 < 256 ? jb.M - b0 : 256;
-    for (int j = 0; j < nb; ++j) {
-      if (__builtin_amdgcn_readfirstlane(li[j]) == r) {
+  for (int b0 = 0; b0 < jb.M; b0 += 64) {
+    const bool hit = b0 + lane < jb.M && ldi64g(idx + (b0 + lane < jb.M ? b0 + lane : 0)) == (long long)r;
+    unsigned long long mask = __ballot(hit);
+    while (mask) {
+      const int j = __builtin_ctzll(mask);
+      mask &= mask - 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int o = (i * 256 + threadIdx.x) * 4;
-          if (i < nv && o < D) {
-            const float4 t = ld4g(src + (long long)(b0 + j) * jb.lda[0] + o);
-            acc[i].x += t.x; acc[i].y += t.y; acc[i].z += t.z; acc[i].w += t.w;
-          }
+      for (int i = 0; i < 4; ++i) {
+        const int o = (i * 256 + threadIdx.x) * 4;
+        if (i < nv && o < D) {
+          const float4 t = ld4g(src + (long long)(b0 + j) * jb.lda[0] + o);
+          acc[i].x += t.x; acc[i].y += t.y; acc[i].z += t.z; acc[i].w += t.w;
         }
       }
     }
@@ -805,7 +851,6 @@ __device__ __forceinline__ void embbwd_tile(const fl_pjob& jb, int r, const Prog
     const int o = (i * 256 + threadIdx.x) * 4;
     if (i < nv && o < D) st4g<WT>(wp(jb.C, io) + (long long)r * jb.ldc + o, acc[i]);
   }
-  __syncthreads();
 }
 
 constexpr int FLAT_TILES = 256;  // SQNORM / ADAM: the flat buffer is cut into this many slices
@@ -1243,6 +1288,8 @@ int fl_program_job_tiles(const void* job) {
       FL_REQUIRE(j.A[0] && j.A[1] && j.W[0] && j.bias[0] && j.N % 256 == 0 && j.N <= 1024 && j.lda[0] % 4 == 0 &&
                      j.lda[1] % 4 == 0 && j.ldc % 4 == 0 && (!j.R || j.ldr % 4 == 0),
                  "program LNBWD: N=%d lda=%d,%d ldc=%d", j.N, j.lda[0], j.lda[1], j.ldc);
+      FL_REQUIRE(!j.A[2] || (j.W[1] && j.bias[1] && j.aux[2] && j.lda[2] % 4 == 0),
+                 "program LNBWD: the two-stage form needs W[1], bias[1] and aux[2]");
       return ((j.M + TS - 1) / TS) * (TS / 4);
     case FL_PJOB_LNCOL:
       FL_REQUIRE(j.A[0] && j.A[1] && j.aux[0] && j.aux[1] && j.N % 32 == 0, "program LNCOL: N=%d", j.N);

@@ -122,6 +122,20 @@ class ProgramBuilder:
         self._hold(x, dy, w, b, mask, R, dx, gl, stats)
         self._add(j, [x, dy, mask, R], [dx, gl, stats])
 
+    def lnbwd2(self, M, D, x_outer, dy, w_outer, b_outer, eps_outer, R, mid, stats_outer, x_inner, w, b, eps, dx, act=ops.ACT_NONE,
+               mask=None, gl=None, stats=None):
+        """backward of ROWNORM's LN pair in one row job: mid = LN_outer'(dy; x_outer) + R, dx = LN_inner'(mid * act' * mask;
+        x_inner); all tensors [M, D] contiguous."""
+        j = np.zeros((), JOB_DTYPE)
+        j["kind"], j["M"], j["N"] = LNBWD, M, D
+        j["A"][0], j["A"][1], j["A"][2] = _ptr(x_outer), _ptr(dy), _ptr(x_inner)
+        j["lda"][0] = j["lda"][1] = j["lda"][2] = j["ldr"] = j["ldc"] = D
+        j["W"][0], j["bias"][0], j["eps"], j["W"][1], j["bias"][1], j["eps2"] = _ptr(w), _ptr(b), eps, _ptr(w_outer), _ptr(b_outer), eps_outer
+        j["act"], j["mask"], j["R"], j["C"] = act, _ptr(mask), _ptr(R), _ptr(dx)
+        j["aux"][0], j["aux"][1], j["aux"][2], j["aux"][3] = _ptr(gl), _ptr(stats), _ptr(mid), _ptr(stats_outer)
+        self._hold(x_outer, dy, x_inner, w, b, w_outer, b_outer, mask, R, dx, gl, stats, mid, stats_outer)
+        self._add(j, [x_outer, dy, x_inner, mask, R], [dx, gl, stats, mid, stats_outer])
+
     def lncol(self, M, D, gl, ldg, x, ldx, stats, dw, db):
         j = np.zeros((), JOB_DTYPE)
         j["kind"], j["M"], j["N"] = LNCOL, M, D

@@ -146,14 +146,12 @@ class DenoiserTrainProgram:
             wgrad(dv, D, hn, D, ap + "in_proj_weight", ap + "in_proj_bias", w_off=2 * D * D, b_off=2 * D)
             dgrad(dv, D, (d(att.in_proj_weight), 2 * D * D), D, dhn)
             pb.barrier()
-            dh2, st_n = new(B, D), new(B, 2)
-            pb.lnbwd(B, D, h2, D, dhn, D, d(norm.weight), d(norm.bias), norm.eps, dh2, D, R=dh3, ldr=D, stats=st_n)
+            # both LayerNorm backwards of the layer (v2:549 then v2:514-516) are row-local: one row job
+            dh2, st_n, dg, gl, st_g = new(B, D), new(B, 2), new(B, D), new(B, D), new(B, 2)
+            pb.lnbwd2(B, D, h2, dhn, d(norm.weight), d(norm.bias), norm.eps, dh3, dh2, st_n, g, d(ln.weight), d(ln.bias), ln.eps,
+                      dg, act=SW, mask=IO(BM0 + i) if masks else None, gl=gl, stats=st_g)
             pb.barrier()
-            dg, gl, st_g = new(B, D), new(B, D), new(B, 2)
-            pb.lnbwd(B, D, g, D, dh2, D, d(ln.weight), d(ln.bias), ln.eps, dg, D, act=SW, mask=IO(BM0 + i) if masks else None,
-                     gl=gl, stats=st_g)
             pb.lncol(B, D, dhn, D, h2, D, st_n, G(pre + "1.weight"), G(pre + "1.bias"))
-            pb.barrier()
             dh1 = new(B, D)
             wgrad(dg, D, h1, D, pre + "0.0.weight", pre + "0.0.bias")
             dgrad(dg, D, d(lin.weight), D, dh1, R=dh2, ldr=D)

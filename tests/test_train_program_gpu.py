@@ -117,6 +117,40 @@ def test_layernorm_backward_jobs(dev, D, act, masked):
     close(st[:, 0], x.double().mean(1), 1e-5, "mean")
 
 
+@pytest.mark.parametrize("D,B", [(512, 70), (1024, 256)])
+def test_two_stage_layernorm_backward_job(dev, D, B):
+    """The layer's LayerNorm pair (v2:514-516 then v2:549) backward as ONE row job vs torch autograd in fp64."""
+    g_, dy, R = rnd(B, D, seed=1, scale=2.0), rnd(B, D, seed=2), rnd(B, D, seed=3)
+    w, b, w2, b2 = 1 + 0.1 * rnd(D, seed=4), 0.1 * rnd(D, seed=5), 1 + 0.1 * rnd(D, seed=6), 0.1 * rnd(D, seed=7)
+    mask = (torch.rand(B, D, generator=torch.Generator().manual_seed(8)) > 0.3).float() / 0.7
+    gd = g_.double().requires_grad_(True)
+    wd, bd, w2d, b2d = (t.double().requires_grad_(True) for t in (w, b, w2, b2))
+    h2 = swish(torch.nn.functional.layer_norm(gd, (D,), wd, bd, 1e-5) * mask.double())
+    h2.retain_grad()
+    hn = torch.nn.functional.layer_norm(h2, (D,), w2d, b2d, 1e-5)
+    ((hn * dy.double()).sum() + (h2 * R.double()).sum()).backward()
+    d = lambda t: t.to(dev)
+    dg, mid, gl = (torch.empty(B, D, device=dev) for _ in range(3))
+    st_o, st_i = torch.empty(B, 2, device=dev), torch.empty(B, 2, device=dev)
+    dw, db, dw2, db2 = (torch.empty(D, device=dev) for _ in range(4))
+    dh2x, ddy, dgx = d(h2.detach().float()), d(dy), d(g_)
+    pb = P.ProgramBuilder()
+    pb.lnbwd2(B, D, dh2x, ddy, d(w2), d(b2), 1e-5, d(R), mid, st_o, dgx, d(w), d(b), 1e-5, dg, act=ops.ACT_SWISH, mask=d(mask),
+              gl=gl, stats=st_i)
+    pb.barrier()
+    pb.lncol(B, D, ddy, D, dh2x, D, st_o, dw2, db2)
+    pb.lncol(B, D, gl, D, dgx, D, st_i, dw, db)
+    prog = pb.finalize(dev)
+    prog.run([])
+    prog.check()
+    close(mid, h2.grad, 3e-5, "d h2")
+    close(dg, gd.grad, 3e-5, "d g")
+    close(dw2, w2d.grad, 3e-5, "outer weight")
+    close(db2, b2d.grad, 3e-5, "outer bias")
+    close(dw, wd.grad, 3e-5, "inner weight")
+    close(db, bd.grad, 3e-5, "inner bias")
+
+
 def test_loss_fin_ewadd_embedding_jobs(dev):
     B, D, rows = 70, 256, 11
     pred, tgt, r = rnd(B, D, seed=1), rnd(B, D, seed=2), rnd(B, D, seed=3)

@@ -32,3 +32,14 @@ with torch.cuda.graph(g2):
     tr.fwd_bwd(z0, labels)
     tr.update()
 print("denoiser fwd/bwd + clip/AdamW graph: %.3f ms" % timeit(g2.replay))
+if tr.persistent:
+    tp = list(tr._tprog.values())[0]
+    t = tr.diffusion.rng.randint((B,), dev, 1000)
+    eps = torch.randn(B, 256, device=dev)
+    bm, hm = un.dropout_masks(B, dev)
+    xt = torch.randn(B, 256, device=dev)
+    print("  train program alone (%d phases, %d jobs): %.3f ms" % (tp.prog.n_phases, tp.prog.n_jobs,
+          timeit(lambda: tp.run(xt, t, labels, eps, bm, hm))))
+    print("  optimizer program alone: %.3f ms" % timeit(tr._oprog.run))
+tr.capture(data, labels)
+print("whole step, one stream (encoder + denoiser + optimizer graphs): %.3f ms" % timeit(tr.replay))

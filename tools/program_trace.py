@@ -17,7 +17,17 @@ un = M.ConditionalUNet().to(dev).eval()
 x = torch.randn(B, 256, device=dev)
 t = torch.randint(0, 1000, (B,), device=dev)
 c = torch.randint(0, 102, (B,), device=dev)
-up = P.UNetProgram(un, B, dev)
+TRAIN = os.environ.get("TRAIN", "0") == "1"
+if TRAIN:  # the two-launch training step's forward+backward program (program_train.py)
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import steps
+    from oxford_102_flower_gan_vae_latent_diffusion_amd.program_train import DenoiserTrainProgram, XT, T as TT, CLS as TC, EPS, BM0, HM0
+    un.train()
+    fp = steps.FlatParams(un)
+    up = DenoiserTrainProgram(un, fp.gviews, B, dev)
+    eps_t = torch.randn(B, 256, device=dev)
+    bm, hm = un.dropout_masks(B, dev)
+else:
+    up = P.UNetProgram(un, B, dev)
 nph = up.prog.n_phases
 G = torch.cuda.get_device_properties(0).multi_processor_count
 trace = torch.zeros(G * nph * 12, dtype=torch.int64, device=dev)
@@ -26,7 +36,12 @@ out = torch.empty(B, 256, device=dev)
 
 def run():
     io = [up._dummy] * 16
-    io[P.X], io[P.T], io[P.CLS], io[P.OUT] = x, t, c, out
+    if TRAIN:
+        io[XT], io[TT], io[TC], io[EPS] = x, t, c, eps_t
+        for i in range(4):
+            io[BM0 + i], io[HM0 + i] = bm[i], hm[i]
+    else:
+        io[P.X], io[P.T], io[P.CLS], io[P.OUT] = x, t, c, out
     io[15] = trace
     up.prog.run(io)
 
