@@ -396,7 +396,9 @@ int fl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float
  *                    column 0 also emit aux[0][m] = alpha * (1 + sigmoid(*gate) if gate) * sum_k A[k][m] (the bias
  *                    gradient rides on the weight gradient); FL_PG_ACTBWD: v *= act'(aux[1][row*ld2 + col]) after the
  *                    bias (act names the activation whose derivative is taken; no forward activation is applied);
- *                    aux[3] != 0: the pre-activation value is stored there too (row stride ldc).
+ *                    aux[3] != 0: the pre-activation value is stored there too (row stride ldc). FL_PG_T64 (with TA|TW,
+ *                    one segment, M, N % 64 == 0, no epilogue other than FL_PG_COLSUM): 64x64 output tiles from one
+ *                    LDS stage - the weight-gradient form.
  *   FL_PJOB_LNBWD    row LayerNorm backward: x = A[0], dy = A[1]; u = mask*(xhat*W[0]+bias[0]); gl = dy*act'(u)*mask;
  *                    C = rstd*(gl*w - mean(gl*w) - xhat*mean(gl*w*xhat)) + R; aux[0] = gl (optional), aux[1] = [M][2]
  *                    (mean, rstd) recomputed from x exactly as FL_PJOB_ROWNORM computes them. Two-stage form (A[2] != 0,
@@ -426,7 +428,7 @@ int fl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float
 enum { FL_PJOB_GEMM = 0, FL_PJOB_ROWNORM = 1, FL_PJOB_SINUSOID = 2, FL_PJOB_GATHER = 3, FL_PJOB_PSAMPLE = 4,
        FL_PJOB_LNBWD = 5, FL_PJOB_LNCOL = 6, FL_PJOB_LOSS = 7, FL_PJOB_FIN = 8, FL_PJOB_EWADD = 9, FL_PJOB_EMBBWD = 10,
        FL_PJOB_SQNORM = 11, FL_PJOB_ADAM = 12 };
-enum { FL_PG_TA = 1, FL_PG_TW = 2, FL_PG_COLSUM = 4, FL_PG_ACTBWD = 8, FL_PG_DECOUPLED = 16 };
+enum { FL_PG_TA = 1, FL_PG_TW = 2, FL_PG_COLSUM = 4, FL_PG_ACTBWD = 8, FL_PG_DECOUPLED = 16, FL_PG_T64 = 32 };
 typedef struct fl_pjob {
   uint64_t A[FL_PROG_MAX_SEG], W[FL_PROG_MAX_SEG], bias[FL_PROG_MAX_SEG];
   uint64_t R, C, mask, gate;
@@ -457,7 +459,7 @@ typedef struct fl_pphase {
 /* sizeof(fl_pjob) / sizeof(fl_pphase) as compiled: the host-side builder asserts its packing against these */
 int fl_program_job_bytes(void);
 int fl_program_phase_bytes(void);
-/* tiles a job occupies = ceil(M/32) row tiles x tiles per row tile (GEMM: N/32; ROWNORM: 8; SINUSOID: ceil(32*N/2/256);
+/* tiles a job occupies = ceil(M/32) row tiles x tiles per row tile (GEMM: N/32 (FL_PG_T64: M/64 x N/64 in all); ROWNORM: 8; SINUSOID: ceil(32*N/2/256);
  * GATHER, PSAMPLE, EWADD: ceil(32*N/4/256); LNBWD, LOSS: 8; LNCOL: N/32, EMBBWD: K[0], FIN: 1, SQNORM, ADAM: 256 in all);
  * negative fl_status if the job violates the shape rules above. `job` is a HOST pointer. */
 int fl_program_job_tiles(const void* job);

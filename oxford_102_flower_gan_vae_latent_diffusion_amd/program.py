@@ -16,7 +16,7 @@ from . import lib, ops
 import os
 
 GEMM, ROWNORM, SINUSOID, GATHER, PSAMPLE, LNBWD, LNCOL, LOSS, FIN, EWADD, EMBBWD, SQNORM, ADAM = range(13)
-PG_TA, PG_TW, PG_COLSUM, PG_ACTBWD, PG_DECOUPLED = 1, 2, 4, 8, 16
+PG_TA, PG_TW, PG_COLSUM, PG_ACTBWD, PG_DECOUPLED, PG_T64 = 1, 2, 4, 8, 16, 32
 LOCAL_DEFAULT = os.environ.get("FL_PROG_LOCAL", "0") == "1"  # opt-in XCD-local execution (same speed, see program.hip)
 MAX_IO = 16
 
@@ -85,15 +85,16 @@ class ProgramBuilder:
 
     def gemm(self, M, N, segs, C, ldc, biases=(), act=ops.ACT_NONE, R=None, ldr=0, mask=None, mask_group=0, gate=None,
              bias_row_index=None, bias_row_stride=0, ta=False, tw=False, colsum=None, colsum_alpha=1.0, actbwd=None,
-             ld_actbwd=0, pre_out=None):
+             ld_actbwd=0, pre_out=None, t64=False):
         """C[M,N] = epi(sum_s A_s W_s^T). segs: [(A, lda, K, W, ldw)]; biases: [(bias, scale)]; with bias_row_index (a
         device int64) biases[0] is row *index of a table with row stride bias_row_stride.
         ta / tw: operand stored with the contraction index as its row (A[k][m], W[k][n]); colsum (needs ta): vector that
         receives colsum_alpha * (1 + sigmoid(gate)) * sum_k A[k][m]; actbwd: tensor P, the result is multiplied by
-        act'(P[row][col]) instead of being activated; pre_out: also store the pre-activation value there."""
+        act'(P[row][col]) instead of being activated; pre_out: also store the pre-activation value there; t64 (ta and tw,
+        M, N % 64 == 0, no epilogue): 64x64 tiles from one LDS stage (weight gradients)."""
         j = np.zeros((), JOB_DTYPE)
         j["flags"] = (PG_TA if ta else 0) | (PG_TW if tw else 0) | (PG_COLSUM if colsum is not None else 0) | \
-            (PG_ACTBWD if actbwd is not None else 0)
+            (PG_ACTBWD if actbwd is not None else 0) | (PG_T64 if t64 else 0)
         j["aux"][0], j["alpha"], j["aux"][1], j["ld2"], j["aux"][3] = _ptr(colsum), colsum_alpha, _ptr(actbwd), ld_actbwd, _ptr(pre_out)
         self._hold(colsum, actbwd, pre_out)
         j["kind"], j["M"], j["N"], j["nseg"] = GEMM, M, N, len(segs)

@@ -42,7 +42,8 @@ class DenoiserTrainProgram:
         def wgrad(dy, n_out, x, k_in, wname, bname=None, alpha=1.0, gate=None, w_off=0, b_off=0):
             """dW[n_out, k_in] = dy^T x (+ bias gradient = alpha * column sums of dy) into the flat gradient buffer."""
             pb.gemm(n_out, k_in, [(dy, n_out, B, x, k_in)], (G(wname), w_off) if w_off else G(wname), k_in, ta=True, tw=True,
-                    colsum=((G(bname), b_off) if b_off else G(bname)) if bname else None, colsum_alpha=alpha, gate=gate)
+                    colsum=((G(bname), b_off) if b_off else G(bname)) if bname else None, colsum_alpha=alpha, gate=gate,
+                    t64=n_out % 64 == 0 and k_in % 64 == 0)
 
         def dgrad(dy, n_out, W, k_in, dx, **kw):
             """dx[B, k_in] = dy[B, n_out] W[n_out, k_in]"""
@@ -184,6 +185,10 @@ class DenoiserTrainProgram:
         self.out = out
         self._dummy = torch.zeros(4, **f32)
         ws.update(dict(out=out, dout=dout, norms=norms, u=u, hpre=hpre, tc=tc, te=te, ce=ce, saved=saved))
+
+    @property
+    def programs(self):
+        return (self.prog,)
 
     def run(self, xt, t, labels, eps, block_masks=None, head_masks=None):
         B = self.B

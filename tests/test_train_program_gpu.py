@@ -32,7 +32,7 @@ def swish_grad(v):
     return s * (1 + v * (1 - s))
 
 
-@pytest.mark.parametrize("B", [256, 64, 300, 5])
+@pytest.mark.parametrize("B", [256, 64, 300, 5, 513])
 def test_dgrad_wgrad_jobs(dev, B):
     """dx = (dy W) * head mask + R (W read as [k][n]); dW = dy^T x with the bias gradient (alpha, gate) riding on it;
     an activation-backward epilogue and a pre-activation copy. B = 300 / 5 / 64: ragged and short contraction chunks."""
@@ -53,6 +53,8 @@ def test_dgrad_wgrad_jobs(dev, B):
     pb.gemm(B, K, [(ddy, N, N, dW_, K)], out_dx2, K, tw=True, act=ops.ACT_SWISH, actbwd=dpre, ld_actbwd=K)
     pb.gemm(N, K, [(ddy, N, B, dx_, K)], out_dW, K, ta=True, tw=True, colsum=out_db, colsum_alpha=2.0)
     pb.gemm(N, K, [(ddy, N, B, dx_, K)], out_dW2, K, ta=True, tw=True, colsum=out_db2, gate=dgate)
+    out_dW3, out_db3 = torch.full((N, K), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
+    pb.gemm(N, K, [(ddy, N, B, dx_, K)], out_dW3, K, ta=True, tw=True, colsum=out_db3, colsum_alpha=2.0, gate=dgate, t64=True)
     pb.gemm(B, N, [(dx_, K, K, dW_, K)], fwd, N, [(d(bias), 1.0)], act=ops.ACT_SWISH, pre_out=fwd_pre)
     prog = pb.finalize(dev)
     for _ in range(2):
@@ -66,6 +68,8 @@ def test_dgrad_wgrad_jobs(dev, B):
     close(out_dW2, refW, 2e-5, "wgrad 2")
     close(out_db, 2.0 * dy.double().sum(0), 2e-5, "bias grad (alpha)")
     close(out_db2, (1 + torch.sigmoid(gate.double())) * dy.double().sum(0), 2e-5, "bias grad (gate)")
+    close(out_dW3, refW, 2e-5, "wgrad, 64x64 tiles")
+    close(out_db3, 2.0 * (1 + torch.sigmoid(gate.double())) * dy.double().sum(0), 2e-5, "bias grad, 64x64 tiles")
     p = x.double() @ W.double().t() + bias.double()
     close(fwd_pre, p, 2e-5, "pre-activation copy")
     close(fwd, swish(p), 2e-5, "activated")
@@ -238,7 +242,8 @@ def test_program_step_equals_multikernel_step(dev, B, train):
         if persistent:
             assert tr._tprog and tr._oprog is not None, "the persistent path did not run"
             for pr in tr._tprog.values():
-                pr.prog.check()
+                for q in pr.programs:
+                    q.check()
             tr._oprog.prog.check()
         res.append(out)
     a, b = res
