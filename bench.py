@@ -453,7 +453,9 @@ def main():
 
     log("models + synthetic batches resident in HBM (B=%d per GPU)" % B)
     use_graph = not a.no_graph
-    overlap = use_graph and not a.no_overlap
+    # the denoiser as persistent phase programs (default) needs the whole device: encoder graph -> programs on one stream.
+    # FL_TRAIN_PROGRAM=0 restores the multi-kernel denoiser, which runs as a second stream next to the encoder of the next batch
+    overlap = use_graph and not a.no_overlap and not tr.persistent
     if overlap:
         tr.capture_pipelined(sdata, slabels)
         tr.prime_pipeline(batches[0], labels[0])
@@ -522,6 +524,7 @@ def main():
             "parallelism": "dp%d" % world,
             "hipgraph": use_graph,
             "encoder_denoiser_overlap": overlap,
+            "denoiser_persistent_programs": bool(tr.persistent),
             "loss": final_loss,
             "gemm_math": gemm_math_note,
         },

@@ -71,6 +71,10 @@ def load():
     global _lib, _protos
     if _lib is not None:
         return _lib
+    # PyTorch ships its own HIP runtime: it must be the first one the process maps. If this library is dlopen'ed before
+    # `import torch` (build() followed by smoke() in one process) the system runtime comes in first and the second runtime
+    # then finds no device ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise FlowersLibError(
             "libflowers_hip.so not found at %s — build it with `python __graft_entry__.py` "

@@ -221,7 +221,7 @@ def test_pipelined_trainer_equals_plain_trainer(dev):
     def make():
         ae = seeded(M.SimpleAutoencoder(), 42).to(dev).eval()
         un = seeded(M.ConditionalUNet(), 44).to(dev).train()
-        tr = steps.DDPMTrainer(ae, un, lr=1e-3)
+        tr = steps.DDPMTrainer(ae, un, lr=1e-3, persistent=False)  # the two-stream pipeline is the multi-kernel denoiser's mode
         for r, s in ((ae.rng, 1), (un.rng, 2), (tr.diffusion.rng, 3)):
             r.manual_seed(s)
         return ae, un, tr
@@ -352,7 +352,7 @@ def test_resume_is_bit_exact_and_loss_decreases(dev, tmp_path):
     def make():
         ae = seeded(M.SimpleAutoencoder(), 42).to(dev).eval()
         un = seeded(M.ConditionalUNet(), 44).to(dev).train()
-        tr = steps.DDPMTrainer(ae, un, lr=1e-3)
+        tr = steps.DDPMTrainer(ae, un, lr=1e-3, persistent=False)  # the two-stream pipeline is the multi-kernel denoiser's mode
         for r, s in ((ae.rng, 1), (un.rng, 2), (tr.diffusion.rng, 3)):
             r.manual_seed(s)
         return ae, un, tr
