@@ -85,3 +85,54 @@ def test_io_slots_are_encoded_as_small_integers():
     assert jb["A"][0] == 1 and jb["C"] == 4 and jb["R"] == 16 and jb["W"][0] == w.data_ptr()
     with pytest.raises(AssertionError):
         P.IO(16)
+
+
+def test_training_job_kinds_tile_counts():
+    """Tile counts of the training kinds as the library computes them (include/flowers_hip.h) and the flag encoding."""
+    z = torch.zeros
+    pb = P.ProgramBuilder()
+    dy, x, W = z(256, 512), z(256, 128), z(512, 128)
+    pb.gemm(256, 128, [(dy, 512, 512, W, 128)], z(256, 128), 128, tw=True)                          # dgrad: 8 x 4
+    pb.gemm(512, 128, [(dy, 512, 256, x, 128)], z(512, 128), 128, ta=True, tw=True, colsum=z(512))  # wgrad 32x32: 16 x 4
+    pb.gemm(512, 128, [(dy, 512, 256, x, 128)], z(512, 128), 128, ta=True, tw=True, t64=True)       # wgrad 64x64: 8 x 2
+    pb.barrier()
+    pb.lnbwd(70, 512, z(70, 512), 512, z(70, 512), 512, z(512), z(512), 1e-5, z(70, 512), 512)      # 3 row tiles x 8
+    pb.lncol(70, 512, z(70, 512), 512, z(70, 512), 512, z(70, 2), z(512), z(512))                   # 512 / 32
+    pb.loss(70, 256, z(70, 256), z(70, 256), z(70, 256), z(70), 1.0 / 70)                           # 3 x 8
+    pb.fin(70, z(70), z(1))                                                                          # 1
+    pb.ewadd(70, 256, z(70, 256), z(70, 256), z(70, 256))                                            # 3 x 8
+    pb.embbwd(70, 256, 102, z(70, 256), z(70, dtype=torch.int64), z(102, 256))                      # one per table row
+    pb.barrier()
+    pb.sqnorm(1000, z(1000), z(256))
+    pb.barrier()
+    pb.adam(1000, z(1000), z(1000), z(1000), z(1000), z(256), z(1), z(1, dtype=torch.int32), 0.9, 0.999, 1e-8, 1e-5, True,
+            max_norm=1.0)
+    prog = pb.finalize("cpu")
+    jb = jobs_of(prog)
+    assert list(jb["ntiles"]) == [32, 64, 16, 24, 16, 24, 1, 24, 102, 256, 256]
+    assert list(jb["flags"][:3]) == [P.PG_TW, P.PG_TA | P.PG_TW | P.PG_COLSUM, P.PG_TA | P.PG_TW | P.PG_T64]
+    assert jb["flags"][-1] == P.PG_DECOUPLED and prog.n_phases == 4
+
+
+@pytest.mark.parametrize("bad", ["ta_alone", "ta_ragged", "t64_epilogue", "t64_shape", "lnbwd_D", "lnbwd_two_stage", "adam_n"])
+def test_training_shape_rules_are_enforced(bad):
+    z = torch.zeros
+    pb = P.ProgramBuilder()
+    if bad == "ta_alone":
+        pb.gemm(64, 64, [(z(10, 64), 64, 10, z(10, 64), 64)], z(64, 64), 64, ta=True)
+    elif bad == "ta_ragged":
+        pb.gemm(48, 64, [(z(10, 48), 48, 10, z(10, 64), 64)], z(48, 64), 64, ta=True, tw=True)
+    elif bad == "t64_epilogue":
+        pb.gemm(64, 64, [(z(10, 64), 64, 10, z(10, 64), 64)], z(64, 64), 64, [(z(64), 1.0)], ta=True, tw=True, t64=True)
+    elif bad == "t64_shape":
+        pb.gemm(96, 64, [(z(10, 96), 96, 10, z(10, 64), 64)], z(96, 64), 64, ta=True, tw=True, t64=True)
+    elif bad == "lnbwd_D":
+        pb.lnbwd(8, 320, z(8, 320), 320, z(8, 320), 320, z(320), z(320), 1e-5, z(8, 320), 320)
+    elif bad == "lnbwd_two_stage":
+        j_before = len(pb._phases[-1])
+        pb.lnbwd2(8, 256, z(8, 256), z(8, 256), None, None, 1e-5, None, None, None, z(8, 256), z(256), z(256), 1e-5, z(8, 256))
+        assert len(pb._phases[-1]) == j_before + 1
+    else:
+        pb.adam(1002, z(1002), z(1002), z(1002), z(1002), z(256), z(1), z(1, dtype=torch.int32), 0.9, 0.999, 1e-8, 0.0, True)
+    with pytest.raises(ValueError):
+        pb.finalize("cpu")
