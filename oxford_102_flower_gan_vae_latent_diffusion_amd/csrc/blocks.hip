@@ -129,7 +129,11 @@ __global__ void res_tail_out_kernel(const float* __restrict__ y, const float* __
         u.x += r.x; u.y += r.y; u.z += r.z; u.w += r.w;
       }
       if (final_swish) {
-        u.x = fl::swish_acc(u.x); u.y = fl::swish_acc(u.y); u.z = fl::swish_acc(u.z); u.w = fl::swish_acc(u.w);
+        if (xs) {  // fused inference path: the fast Swish everywhere (this pass is otherwise ALU-bound on expf)
+          u.x = fl::swish_fast(u.x); u.y = fl::swish_fast(u.y); u.z = fl::swish_fast(u.z); u.w = fl::swish_fast(u.w);
+        } else {
+          u.x = fl::swish_acc(u.x); u.y = fl::swish_acc(u.y); u.z = fl::swish_acc(u.z); u.w = fl::swish_acc(u.w);
+        }
       }
       st4(out + off, u);
     }

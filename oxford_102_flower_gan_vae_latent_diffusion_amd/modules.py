@@ -392,6 +392,7 @@ class ClassEmbedding(nn.Module):
 
 
 PERSISTENT_FORWARD = os.environ.get("FL_PERSISTENT", "1") != "0"
+FOLDED_FORWARD = os.environ.get("FL_FOLDED", "1") != "0"  # eval-mode forward with folded linear chains (program.FoldedUNetProgram)
 
 
 class ConditionalUNet(nn.Module):
@@ -475,9 +476,20 @@ class ConditionalUNet(nn.Module):
     def _persistent_forward(self, x, t, c, block_masks, head_masks):
         """Inference forward as ONE launch of the persistent phase program (program.UNetProgram), cached per call
         signature; rebuilt when a parameter tensor is re-allocated. FL_PERSISTENT=0 selects the multi-kernel engine."""
-        from .program import UNetProgram
+        from .program import FoldedUNetProgram, UNetProgram
         B = x.shape[0]
         shared_t = t.numel() == 1 and B != 1
+        if FOLDED_FORWARD and not self.training and c is not None and not shared_t and block_masks is None:
+            # frozen-weight inference: linear chains folded, 13 phases instead of 26 (rebuilt when any weight changes)
+            cache = self.__dict__.setdefault("_folded", {})
+            fp = cache.get((B, x.device))
+            if fp is None or fp.key != FoldedUNetProgram.version_key(self):
+                cache.clear()
+                fp = cache[(B, x.device)] = FoldedUNetProgram(self, B, x.device)
+            self._pcalls = getattr(self, "_pcalls", 0) + 1
+            if self._pcalls % 256 == 0 and not torch.cuda.is_current_stream_capturing():
+                fp.prog.check()
+            return fp(x, t.contiguous(), c.contiguous())
         key = (B, shared_t, c is not None, block_masks is not None, x.device)
         cache = self.__dict__.setdefault("_programs", {})
         up = cache.get(key)

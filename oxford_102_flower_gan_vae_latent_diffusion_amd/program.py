@@ -440,9 +440,125 @@ class UNetProgram:
         return out
 
 
+class FoldedUNetProgram:
+    """Eval-mode ConditionalUNet forward (per-sample t, class-conditional, no dropout) with the linear chains between the
+    nonlinearities folded, 13 phases instead of 26 (a phase costs ~4.4 us of barrier + hand-over whatever it computes, §3b):
+      * attention with one token is out_proj(v_proj(.)) and nothing nonlinear follows before the next layer, so
+        down(out_proj(v_proj(hn)) + h2) = (W_d W_o W_v) hn + W_d h2 + const is one contraction over [hn | h2]  (as in
+        SamplerProgram);
+      * the Linear that follows h1 = h + time_proj(tc) is linear in the same inputs, so g = W_lin h1 + b is computed NEXT TO
+        h1 in the same phase with pre-multiplied weights (W_lin W_cat, W_lin W_tp) instead of one phase later;
+      * layer 0 and the final projections take te1a / ce1a through pre-multiplied weights (W_tp0 W_te2, ...), so nothing on
+        the chain waits for te / ce / tc.
+    The folded weights are products of the module's weights computed once per weight version (`version_key`): this program
+    is for frozen weights (inference). Matches v2:534-561 to fp32 re-association (tests/test_program_gpu.py)."""
+
+    def __init__(self, un, B, device):
+        d = lambda p: p.detach()
+        SW = ops.ACT_SWISH
+        f32 = dict(dtype=torch.float32, device=device)
+        self.un, self.B, self.key = un, B, self.version_key(un)
+        E, L = un.time_emb_dim, un.latent_dim
+        te_m, ce_m = un.time_emb, un.class_emb
+        H1, C1 = te_m.lin1.weight.shape[0], ce_m.lin1.weight.shape[0]
+        new = lambda *shape: torch.empty(*shape, **f32)
+        mm = lambda A, Bm: ops.gemm(A.contiguous(), Bm.contiguous(), A.shape[0], Bm.shape[1], A.shape[1], b_layout=ops.KS,
+                                    ldb=Bm.shape[1])                                    # A @ Bm
+        mv = lambda W, v, b=None: ops.linear(v.reshape(1, -1).contiguous(), W, b).reshape(-1)   # W v (+ b)
+        keep = self.keep = []
+        pb = ProgramBuilder()
+        with torch.no_grad():
+            Wte2, bte2, Wce2, bce2 = d(te_m.lin2.weight), d(te_m.lin2.bias), d(ce_m.lin2.weight), d(ce_m.lin2.bias)
+            bsum = (bte2 + bce2).contiguous()
+            feat, emb, te1a, ce1a, tc = new(B, E), new(B, E), new(B, H1), new(B, C1), new(B, E)
+            pb.sinusoid(B, E, IO(T), 1, un._freqs(device), feat, E)
+            pb.gather(B, E, d(ce_m.embedding.weight), E, IO(CLS), emb, E)
+            pb.barrier()
+            pb.gemm(B, H1, [(feat, E, E, d(te_m.lin1.weight), E)], te1a, H1, [(d(te_m.lin1.bias), 1.0)], act=SW)
+            pb.gemm(B, C1, [(emb, E, E, d(ce_m.lin1.weight), E)], ce1a, C1, [(d(ce_m.lin1.bias), 1.0)], act=SW)
+            pb.barrier()
+            pb.gemm(B, E, [(te1a, H1, H1, Wte2, H1), (ce1a, C1, C1, Wce2, C1)], tc, E, [(bte2, 1.0), (bce2, 1.0)])
+            # final_time_proj(te) + final_class_proj(ce) (+ the folded constants of the last layer, added below)
+            ft, fcp, fn, fin = un.final_time_proj, un.final_class_proj, un.final_norm, un.final
+            Dl = ft.weight.shape[0]
+            extra = new(B, Dl)
+            Wft2, Wfc2 = mm(d(ft.weight), Wte2), mm(d(fcp.weight), Wce2)
+            extra_const = mv(d(ft.weight), bte2, d(ft.bias)) + mv(d(fcp.weight), bce2, d(fcp.bias))
+            prev = None            # (hn, h2, D, Wcat, const): the folded input of the next layer
+            for i, (block, norm, down) in enumerate(un.layers):
+                lin, ln = block[0], block[1]
+                D = lin.weight.shape[0]
+                tp, att = un.time_projections[i], un.attention_layers[i]
+                Wlin, blin, Wtp, btp = d(lin.weight), d(lin.bias), d(tp.weight), d(tp.bias)
+                h1, g, h2, hn = (new(B, D) for _ in range(4))
+                if prev is None:
+                    Wlp, blp = d(un.latent_proj.weight), d(un.latent_proj.bias)
+                    T0, C0 = mm(Wtp, Wte2), mm(Wtp, Wce2)
+                    c_h1 = (blp + 2.0 * btp + mv(Wtp, bsum)).contiguous()
+                    segs_h1 = [(IO(X), L, L, Wlp, L), (te1a, H1, H1, T0, H1), (ce1a, C1, C1, C0, C1)]
+                    Wg0, Tg, Cg = mm(Wlin, Wlp), mm(Wlin, T0), mm(Wlin, C0)
+                    segs_g = [(IO(X), L, L, Wg0, L), (te1a, H1, H1, Tg, H1), (ce1a, C1, C1, Cg, C1)]
+                    keep += [T0, C0, Wg0, Tg, Cg]
+                else:
+                    phn, ph2, Dp, Wcat, cprev = prev
+                    c_h1 = (cprev + 2.0 * btp).contiguous()
+                    segs_h1 = [(phn, Dp, Dp, Wcat, 2 * Dp), (ph2, Dp, Dp, (Wcat, Dp), 2 * Dp), (tc, E, E, Wtp, E)]
+                    WG, WGt = mm(Wlin, Wcat), mm(Wlin, Wtp)
+                    segs_g = [(phn, Dp, Dp, WG, 2 * Dp), (ph2, Dp, Dp, (WG, Dp), 2 * Dp), (tc, E, E, WGt, E)]
+                    keep += [WG, WGt]
+                c_g = mv(Wlin, c_h1, blin).contiguous()
+                keep += [c_h1, c_g, h1, g, h2, hn]
+                pb.gemm(B, D, segs_h1, h1, D, [(c_h1, 1.0)])
+                pb.gemm(B, D, segs_g, g, D, [(c_g, 1.0)])
+                if prev is None:
+                    pb.gemm(B, Dl, [(te1a, H1, H1, Wft2, H1), (ce1a, C1, C1, Wfc2, C1)], extra, Dl)   # off the chain
+                pb.barrier()
+                pb.rownorm(B, D, g, D, d(ln.weight), d(ln.bias), ln.eps, h2, D, act=SW, R=h1, ldr=D, w2=d(norm.weight),
+                           b2=d(norm.bias), eps2=norm.eps, C2=hn)
+                pb.barrier()
+                Wv, bv = d(att.in_proj_weight)[2 * D:], d(att.in_proj_bias)[2 * D:]
+                Wo, bo, Wd, bd = d(att.out_proj.weight), d(att.out_proj.bias), d(down.weight), d(down.bias)
+                Dn = Wd.shape[0]
+                Wcat = new(Dn, 2 * D)
+                Wcat[:, :D] = mm(Wd, mm(Wo, Wv))
+                Wcat[:, D:] = Wd
+                cnext = mv(Wd, mv(Wo, bv, bo), bd)
+                keep.append(Wcat)
+                prev = (hn, h2, D, Wcat, cnext)
+            phn, ph2, Dp, Wcat, cprev = prev
+            c_f = (cprev + extra_const).contiguous()
+            hpre, u = new(B, Dl), new(B, Dl)
+            pb.gemm(B, Dl, [(phn, Dp, Dp, Wcat, 2 * Dp), (ph2, Dp, Dp, (Wcat, Dp), 2 * Dp)], hpre, Dl, [(c_f, 1.0)], R=extra, ldr=Dl)
+            pb.barrier()
+            rw = d(un.residual_weight)
+            pb.rownorm(B, Dl, hpre, Dl, d(fn.weight), d(fn.bias), fn.eps, u, Dl, gate=rw, gx=IO(X), ldgx=L)
+            pb.barrier()
+            pb.gemm(B, L, [(u, Dl, Dl, d(fin.weight), Dl)], IO(OUT), L, [(d(fin.bias), 1.0)], gate=rw)
+            keep += [Wft2, Wfc2, c_f, extra, hpre, u, bsum, feat, emb, te1a, ce1a, tc]
+            self.prog = pb.finalize(device)
+        self._dummy = torch.zeros(4, **f32)
+
+    @staticmethod
+    def version_key(un):
+        """changes whenever a weight does: torch's in-place version counters + the raw-pointer update epoch that
+        steps.FlatParams.bump() advances + the storage addresses"""
+        return (sum(p._version for p in un.parameters()), getattr(un, "_raw_epoch", 0)) + tuple(p.data_ptr() for p in un.parameters())
+
+    def __call__(self, x, t, c, out=None):
+        B = self.B
+        assert x.shape[0] == B and t.numel() == B and c.numel() == B
+        if out is None:
+            out = torch.empty(B, self.un.latent_dim, dtype=torch.float32, device=x.device)
+        ops._chk(x, t, c, out)
+        io = [self._dummy] * 4
+        io[X], io[T], io[CLS], io[OUT] = x, t, c, out
+        self.prog.run(io)
+        return out
+
+
 # ------------------------------------------------------------------------------------------------ sampler step
 class SamplerProgram:
-    """One DDPM reverse step (v2:580-592) as ONE persistent launch of 16 phases: denoiser + update + Philox noise +
+    """One DDPM reverse step (v2:580-592) as ONE persistent launch of 12 phases: denoiser + update + Philox noise +
     step counter. Everything that does not depend on x is hoisted out of the 1000-step loop ("class path
     hoistable"), and with frozen eval-mode weights the linear chains are folded:
       * per-timestep tables (n_steps rows): TE = time_emb(t); TPt_i = W_tp_i TE; FT = W_ft TE  -> one table row per
@@ -451,7 +567,9 @@ class SamplerProgram:
       * attention with one token is out_proj(v_proj(.)) and no nonlinearity follows before the next
         layer's Linear, so  down(out_proj(v_proj(hn)) + h2) = (W_d W_o W_v) hn + W_d h2 + const  is ONE contraction
         over [hn | h2] with pre-multiplied weights.
-    Per layer: h1 GEMM, Linear GEMM, (LN, Swish, +h1, LN) row phase = 3 phases instead of 5; 6.4 MMAC/sample -> 4.9."""
+      * the block's Linear is linear in h1's own inputs, so g = W_lin h1 + b is computed next to h1 in the same phase with
+        pre-multiplied weights and tables (as FoldedUNetProgram).
+    Per layer: {h1, g} GEMMs, (LN, Swish, +h1, LN) row phase = 2 phases instead of 5."""
 
     def __init__(self, diffusion, B, device, x, t64, t32, c=None, noise=None):
         d_ = lambda p: p.detach()
@@ -466,6 +584,8 @@ class SamplerProgram:
             tb = 2.0 if c is not None else 1.0
             pb = ProgramBuilder()
             self.keep = [TE, ce]
+            mm = lambda A, Bm: ops.gemm(A.contiguous(), Bm.contiguous(), A.shape[0], Bm.shape[1], A.shape[1], b_layout=ops.KS,
+                                        ldb=Bm.shape[1])                                    # A @ Bm
             prev_segs = [(x, un.latent_dim, un.latent_dim, d_(un.latent_proj.weight), un.latent_dim)]
             const = d_(un.latent_proj.bias).clone()
             for i, (block, norm, down) in enumerate(un.layers):
@@ -478,15 +598,30 @@ class SamplerProgram:
                     extra = ops.linear(ce, d_(tp.weight), const.contiguous())             # (B, D): W_tp ce + consts
                 h1, g, h2, hn = (torch.empty(B, D, **f32) for _ in range(4))
                 self.keep += [TPt, h1, g, h2, hn]
+                # g = lin(h1) is linear in h1's own inputs: computed NEXT TO h1 with pre-multiplied weights / tables
+                Wlin, blin = d_(lin.weight), d_(lin.bias)
+                TGt = ops.linear(TPt, Wlin)                                                # (T, D): W_lin W_tp TE
+                if len(prev_segs) == 1:
+                    A0, lda0, K0, W0, ldw0 = prev_segs[0]
+                    Wg = mm(Wlin, W0)
+                    segs_g = [(A0, lda0, K0, Wg, K0)]
+                else:
+                    (A0, lda0, K0, Wc, ldw0), (A1, lda1, K1, _, _) = prev_segs
+                    Wg = mm(Wlin, Wc)
+                    segs_g = [(A0, lda0, K0, Wg, ldw0), (A1, lda1, K1, (Wg, K0), ldw0)]
+                self.keep += [TGt, Wg]
                 if ce is not None:
                     self.keep.append(extra)
+                    extra_g = ops.linear(extra, Wlin, blin)
+                    self.keep.append(extra_g)
                     pb.gemm(B, D, prev_segs, h1, D, [(TPt, 1.0)], R=extra, ldr=D, bias_row_index=t64, bias_row_stride=D)
+                    pb.gemm(B, D, segs_g, g, D, [(TGt, 1.0)], R=extra_g, ldr=D, bias_row_index=t64, bias_row_stride=D)
                 else:
                     cst = const.contiguous()
-                    self.keep.append(cst)
+                    cst_g = ops.linear(cst.reshape(1, -1), Wlin, blin).reshape(-1)
+                    self.keep += [cst, cst_g]
                     pb.gemm(B, D, prev_segs, h1, D, [(TPt, 1.0), (cst, 1.0)], bias_row_index=t64, bias_row_stride=D)
-                pb.barrier()
-                pb.gemm(B, D, [(h1, D, D, d_(lin.weight), D)], g, D, [(d_(lin.bias), 1.0)])
+                    pb.gemm(B, D, segs_g, g, D, [(TGt, 1.0), (cst_g, 1.0)], bias_row_index=t64, bias_row_stride=D)
                 pb.barrier()
                 pb.rownorm(B, D, g, D, d_(ln.weight), d_(ln.bias), ln.eps, h2, D, act=SW, R=h1, ldr=D, w2=d_(norm.weight),
                            b2=d_(norm.bias), eps2=norm.eps, C2=hn)

@@ -75,6 +75,7 @@ class FlatParams:
             pk = getattr(m, "_pk", None)
             if pk is not None:
                 pk.epoch += 1
+        self.module._raw_epoch = getattr(self.module, "_raw_epoch", 0) + 1  # folded inference programs key on it
 
 
 class FusedAdam:

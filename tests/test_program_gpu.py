@@ -167,6 +167,48 @@ def test_unet_program_vs_oracle(dev):
     assert mse <= 1e-4, "eps-MSE %.3e above the north-star bound" % mse
 
 
+@pytest.mark.parametrize("B", [256, 37])
+def test_folded_unet_program(dev, B):
+    """Eval forward with the linear chains folded (13 phases): vs the multi-kernel engine, vs the oracle, and rebuilt when a
+    weight changes (torch in-place update or a raw-pointer update announced by FlatParams.bump)."""
+    import json
+    import os
+    from oracle import procedural_init as pinit, v2_oracle as O
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import steps
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sd = pinit.procedural_state_dict(json.load(open(os.path.join(G, "state_dict_shapes.json")))["unet"], 44)
+    un = M.ConditionalUNet().to(dev).eval()
+    un.load_state_dict(sd)
+    x, t = rnd(B, 256, seed=11), torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(12))
+    c = torch.randint(0, 102, (B,), generator=torch.Generator().manual_seed(13))
+    xd, td, cd = x.to(dev), t.to(dev), c.to(dev)
+    with torch.no_grad():
+        fp = P.FoldedUNetProgram(un, B, dev)
+        assert fp.prog.n_phases == 13
+        out = fp(xd, td, cd)
+        ref_e, _ = engine.unet_forward(un, xd, td, cd)
+    fp.prog.check()
+    close(out, ref_e, 3e-5, "folded vs engine")
+    close(out, O.unet_forward(sd, x, t, c), 3e-5, "folded vs oracle")
+    # the module's own forward takes the folded route in eval mode and notices weight updates
+    with torch.no_grad():
+        o1 = un(xd, td, cd)
+        assert torch.equal(o1, out) and un._folded
+        un.final.bias.add_(0.25)                                   # torch in-place update: version counter
+        o2 = un(xd, td, cd)
+    close(o2 - o1, torch.full_like(o1, 0.25) * (1 + torch.sigmoid(un.residual_weight.detach())), 1e-5, "after in-place update")
+    fl = steps.FlatParams(un)                                      # parameters re-homed: new storage
+    with torch.no_grad():
+        o3 = un(xd, td, cd)
+        close(o3, o2, 1e-6, "after re-homing")
+        fl.flat[fl.slots["layers.1.2.bias"][0]:fl.slots["layers.1.2.bias"][0] + 4] += 1.0   # raw update ...
+        fl.bump()                                                  # ... announced
+        o4 = un(xd, td, cd)
+        ref4, _ = engine.unet_forward(un, xd, td, cd)
+    close(o4, ref4, 3e-5, "after a raw-pointer update")
+    assert (o4 - o3).abs().max().item() > 1e-3
+
+
 def test_unet_program_ce_given(dev):
     """Sampler form: one shared timestep, class path hoisted out of the loop (ce computed once)."""
     un = _unet(dev, 3).eval()
@@ -202,7 +244,7 @@ def test_sampler_program_vs_golden_trajectory(dev):
     t32 = torch.tensor([n - 1], dtype=torch.int32, device=dev)
     noise = torch.empty(B, 256, device=dev)
     sp = P.SamplerProgram(d, B, dev, x, t64, t32, c=f["traj_c"].to(dev), noise=noise)
-    assert sp.prog.n_phases == 16
+    assert sp.prog.n_phases == 12
     for i in range(n):
         noise.copy_(f["traj_noise"][i])
         sp.step()
