@@ -135,6 +135,9 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
 size_t fl_pack_weight_f16x2_bytes(int N, int K);
 int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, fl_stream_t stream);
 int fl_conv2d_fwd_f16x2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+/* out[0] = max|x| over n floats: x_amax of fl_conv2d_fwd_f16x2 for inputs whose producer keeps no bound (the training paths'
+ * activations and gradients, v2:1060-1134). */
+int fl_absmax(const float* x, int64_t n, float* out, fl_stream_t stream);
 int fl_conv2d_fwd_f16x2(const float* x, const void* wpack, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                         int kh, int kw, int stride, int pad, int act, float act_param, const float* ln_w, const float* ln_b,
                         float eps, float* scale, float* shift, float* mean, float* rstd, const float* x_amax, int x_exp,

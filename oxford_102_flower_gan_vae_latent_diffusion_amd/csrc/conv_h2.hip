@@ -711,10 +711,12 @@ void h2_set_attr() {
 
 // M-tile of the 3x3 kernel: 256 pixels (8 waves, one block per CU) or 128 (4 waves; two INDEPENDENT blocks per CU, whose
 // prologues / epilogues / barriers overlap each other's MFMA clusters). FL_H2_BM overrides the per-shape default.
-int h2_bm(int W, int Cin, bool pre, long long M) {
+int h2_bm(int W, int Cin, bool pre, long long M, int Cout) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("FL_H2_BM"); forced = e ? atoi(e) : 0; }
   int bm = forced ? forced : 256;
+  // fewer 256-pixel tiles than CUs (batch 64 on the 16-wide stage): 128-pixel tiles fill the chip
+  if (!forced && M % 128 == 0 && (M / 256) * (Cout / 128) < 256) bm = 128;
   if (bm == 128) {  // two blocks must fit the CU's LDS
     const int ni = (128 / W) > W ? (128 / W) / W : 1;
     const int lds = (W == 32 ? H2Geom<32, 128>::LDS_B : W == 16 ? H2Geom<16, 128>::LDS_B : H2Geom<8, 128>::LDS_B) + (pre ? 2 * ni * Cin * 4 : 0);
@@ -765,7 +767,7 @@ int launch_conv_h2(const float* x, const void* wpack, const float* bias, float* 
   g.a_amax = a_amax; g.a_exp = a_exp;
   g.x = x; g.wpack = reinterpret_cast<const char*>(wpack); g.bias = bias; g.y = y; g.stats = stats;
   g.M = ksize == 3 ? B * H * W : B * (H / 2) * (W / 2);
-  const int bm = ksize == 3 ? h2_bm(W, Cin, pre_scale != nullptr, g.M) : 256;
+  const int bm = ksize == 3 ? h2_bm(W, Cin, pre_scale != nullptr, g.M, Cout) : 256;
   const int pre_b = pre_scale ? h2_pre_bytes(ksize, ksize == 3 ? W : W / 2, Cin, bm) : 0;
   g.ntiles = (g.M / bm) * g.tiles_n;
   const int blocks = g.ntiles;
@@ -814,6 +816,25 @@ int pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, hipSt
   return fl::check_launch("h2_pack_kernel");
 }
 
+// one atomic per block (memory-side atomics to one address serialise at ~25 ns each: a per-wave atomic from 2048 blocks
+// cost 94 us on a 33 MB tensor); float4 loads, n % 4 handled by the scalar tail of block 0
+__global__ __launch_bounds__(256) void h2_amax_kernel_pub(const float* __restrict__ x, long long n, unsigned* out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const long long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0)
+    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(x[i]));
+  m = fl::wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));  // non-negative floats order like their bits
+}
+
 }  // namespace fl
 
 // =====================================================================================
@@ -827,6 +848,20 @@ int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, fl
   FL_REQUIRE(layout == 0 || (layout == 1 && K % 128 == 0), "fl_pack_weight_f16x2: layout %d (0 = 16-k groups, 1 = 4x4 tap pairs, K = 16 Cin, Cin %% 8 == 0)", layout);
   FL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0, "fl_pack_weight_f16x2: 16-byte alignment");
   return fl::pack_weight_f16x2(w, out, N, K, layout, reinterpret_cast<hipStream_t>(stream));
+}
+
+// out[0] = max|x| (a device float; 0 for n == 0): the range information fl_conv2d_fwd_f16x2 takes as x_amax when the
+// producer of x keeps no bound (training activations and gradients). Order-independent (atomic max of non-negative floats).
+int fl_absmax(const float* x, int64_t n, float* out, fl_stream_t stream) {
+  FL_REQUIRE(out && (x || n == 0) && n >= 0, "fl_absmax: bad args");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(out, 0, 4, s) != hipSuccess) return fl::check_launch("fl_absmax memset");
+  if (n == 0) return FL_OK;
+  FL_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "fl_absmax: x must be 16-byte aligned");
+  int blocks = fl::cdiv(n, 256 * 16);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(fl::h2_amax_kernel_pub, dim3(blocks), dim3(256), 0, s, x, (long long)n, reinterpret_cast<unsigned*>(out));
+  return fl::check_launch("fl_absmax");
 }
 
 int fl_conv2d_fwd_f16x2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {

@@ -65,6 +65,18 @@ class PackCache:
 
         return self.get(("convh2", id(conv)), [w], make)
 
+    def conv_h2_dgrad(self, conv):
+        """f16x2 pack of the MIRROR convolution of a 3x3 / stride 1 / pad 1 nn.Conv2d: its input gradient is the same
+        conv forward on dy with the taps flipped and the channel roles swapped -> (pack, (I, 3, 3, Opad))."""
+        w = conv.weight
+
+        def make():
+            wt = w.detach().flip(2, 3).transpose(0, 1).contiguous()      # (I, O, 3, 3): a re-layout, no arithmetic
+            wp = ops.pack_conv_weight(wt, (wt.shape[1] + 3) // 4 * 4)
+            return ops.pack_weight_f16x2(wp), tuple(wp.shape)
+
+        return self.get(("convh2d", id(conv)), [w], make)
+
     def ln_bound(self, ln, n, prev=None):
         """(1,) device float bounding |ln(.)| (and what Swish / (0,1) gates make of it) for a norm over n elements, plus
         the bound `prev` of a residual input: the range information of the f16x2 convs. Per weight version."""

@@ -5,6 +5,8 @@ A2-A9, A14, A15), plus the torch.autograd.Function wrappers that give the drop-i
 All arithmetic is libflowers_hip.so kernels via ops.py (NHWC fp32). Gradients are returned as dicts keyed by the
 module-relative parameter names of the reference's state-dict.
 """
+import os
+
 import torch
 
 from . import engine, ops
@@ -24,6 +26,44 @@ def _add(a, b):
 def _c2(x):
     """(B,H,W,C) -> (B*H*W, C) view."""
     return x.view(-1, x.shape[-1])
+
+
+# f16x2 split math (csrc/conv_h2.hip) for the 3x3 / stride-1 convs of the TRAINING paths too (forward, and the input
+# gradient as the mirror convolution): the weights are re-packed once per weight version (= per optimizer step for the
+# trainable ones, once for the frozen VGG), the input's range is its measured max (fl_absmax). FL_TRAIN_F16X2=0: bf16x3.
+USE_F16X2_TRAIN = os.environ.get("FL_TRAIN_F16X2", "1") != "0"
+
+
+def _h2_ok(x, Cout, k=3, stride=1):
+    """the f16x2 kernel's tiles are 256 (or 128) pixels x 128 channels, one per block: below ~3/4 of the CUs busy (batch 64
+    on the 8-wide stage: 128 tiles) the generic split-K kernel is the faster one"""
+    B, H, W, _ = x.shape
+    return (USE_F16X2_TRAIN and ops.get_gemm_math() == "split" and B > 0 and (B * H * W // 128) * (Cout // 128) >= 192
+            and ops.f16x2_ok(x, Cout, k, k, stride, 1))
+
+
+def conv3_fwd_ln(x, conv, ln, pk):
+    """3x3 s1 p1 conv + fused LayerNorm2d statistics -> (y, (scale, shift, mean, rstd))"""
+    if _h2_ok(x, conv.weight.shape[0]):
+        wh, geom = pk.conv_h2(conv)
+        return ops.conv2d_fwd_f16x2(x, wh, geom, _d(conv.bias), 1, 1, ln_w=_d(ln.weight), ln_b=_d(ln.bias), eps=ln.eps,
+                                    x_amax=ops.absmax(x))
+    return ops.conv2d_fwd_instnorm(x, pk.conv(conv), _d(conv.bias), 1, 1, _d(ln.weight), _d(ln.bias), ln.eps)
+
+
+def conv3_fwd_act(x, conv, pk, act):
+    if _h2_ok(x, conv.weight.shape[0]):
+        wh, geom = pk.conv_h2(conv)
+        return ops.conv2d_fwd_f16x2(x, wh, geom, _d(conv.bias), 1, 1, act=act, x_amax=ops.absmax(x))
+    return ops.conv2d_fwd(x, pk.conv(conv), _d(conv.bias), 1, 1, act=act)
+
+
+def conv3_dgrad(dy, conv, hw, pk):
+    """input gradient of a 3x3 s1 p1 conv: the mirror convolution's forward on dy when the f16x2 kernel covers the shape"""
+    if _h2_ok(dy, conv.weight.shape[1]):
+        wh, geom = pk.conv_h2_dgrad(conv)
+        return ops.conv2d_fwd_f16x2(dy, wh, geom, None, 1, 1, x_amax=ops.absmax(dy))
+    return ops.conv2d_dgrad(dy, pk.conv(conv), hw, 1, 1)
 
 
 def reparam_dlogvar(dz, logvar, eps):
@@ -63,11 +103,9 @@ def _ca_mlp_bwd(saved, ds):
 def resblock_fwd(x, rb, pk):
     S = RBSaved()
     S.x = x
-    S.y1, S.n1 = ops.conv2d_fwd_instnorm(x, pk.conv(rb.conv1), _d(rb.conv1.bias), 1, 1, _d(rb.ln1.weight),
-                                         _d(rb.ln1.bias), rb.ln1.eps)
+    S.y1, S.n1 = conv3_fwd_ln(x, rb.conv1, rb.ln1, pk)
     S.a1 = ops.affine_act(S.y1, S.n1[0], S.n1[1], act=SW)
-    S.y2, S.n2 = ops.conv2d_fwd_instnorm(S.a1, pk.conv(rb.conv2), _d(rb.conv2.bias), 1, 1, _d(rb.ln2.weight),
-                                         _d(rb.ln2.bias), rb.ln2.eps)
+    S.y2, S.n2 = conv3_fwd_ln(S.a1, rb.conv2, rb.ln2, pk)
     s, S.ca = _ca_mlp_fwd(rb.ca, _d(rb.ln2.bias).view(1, -1))  # avg_pool(LN2d(.)) == ln2.bias (see engine.resblock_infer)
     S.s = s.view(-1)
     S.saw = _d(rb.sa.conv.weight).contiguous()
@@ -90,14 +128,14 @@ def resblock_bwd(S, dout, rb, pk, need_dx=True):
     hw = (S.y2.shape[1], S.y2.shape[2])
     G["conv2.weight"] = ops.unpack_conv_weight(ops.conv2d_wgrad(dy2, S.a1, 3, 3, 1, 1), C, C, 3, 3)
     G["conv2.bias"] = ops.colsum(_c2(dy2))
-    da1 = ops.conv2d_dgrad(dy2, pk.conv(rb.conv2), hw, 1, 1)
+    da1 = conv3_dgrad(dy2, rb.conv2, hw, pk)
     sc1, sh1, m1, r1 = S.n1
     dy1, G["ln1.weight"], G["ln1.bias"] = ops.instnorm_bwd(da1, S.y1, sc1, sh1, _d(rb.ln1.weight), m1, r1, act=SW)
     G["conv1.weight"] = ops.unpack_conv_weight(ops.conv2d_wgrad(dy1, S.x, 3, 3, 1, 1), C, C, 3, 3)
     G["conv1.bias"] = ops.colsum(_c2(dy1))
     dx = None
     if need_dx:
-        dx = _add(ops.conv2d_dgrad(dy1, pk.conv(rb.conv1), hw, 1, 1), dw)
+        dx = _add(conv3_dgrad(dy1, rb.conv1, hw, pk), dw)
     return dx, G
 
 
@@ -339,7 +377,7 @@ def vgg_features(vgg, x, save):
     for layer in vgg.feature_extractor:
         if isinstance(layer, torch.nn.Conv2d):
             hin = h
-            h = ops.conv2d_fwd(hin, pk.conv(layer), _d(layer.bias), 1, 1, act=RELU)
+            h = conv3_fwd_act(hin, layer, pk, RELU)
             if save:
                 tape.append(("conv", layer, hin, h))
         elif isinstance(layer, torch.nn.MaxPool2d):
@@ -359,7 +397,7 @@ def vgg_features_bwd(vgg, tape, dfeat):
             d = ops.maxpool2_bwd(d, hin)
         else:
             dpre = ops.act_bwd(d, hout, RELU)  # relu' from the output sign
-            d = ops.conv2d_dgrad(dpre, pk.conv(layer), (hin.shape[1], hin.shape[2]), 1, 1)
+            d = conv3_dgrad(dpre, layer, (hin.shape[1], hin.shape[2]), pk)
     sc, _, zero = _vgg_consts(vgg)
     return ops.nhwc_to_nchw(ops.affine_act(d, sc, zero), 3)
 

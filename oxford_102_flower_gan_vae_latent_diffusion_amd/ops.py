@@ -306,6 +306,14 @@ def conv2d_fwd_f16x2(x, wpack, geom, bias, stride=1, pad=1, act=ACT_NONE, act_pa
     return y, (scale, shift, mean, rstd)
 
 
+def absmax(x):
+    """(1,) device float = max|x| (fl_absmax): range information of the f16x2 convs for training activations / gradients."""
+    _chk(x)
+    out = new((1,), x)
+    _lib.call("fl_absmax", _p(x), x.numel(), _p(out), _stream())
+    return out
+
+
 def affine_bound(w, b, mult, prev=None):
     """(1,) device float: mult * max|w| + max|b| (+ prev) - bound on |LayerNorm-style output| (see fl_affine_bound)."""
     ref = w if w is not None else b

@@ -718,3 +718,35 @@ def test_encoder_infer_f16x2_fused_vs_oracle(dev):
     assert torch.equal(mu, mu2) and torch.equal(lv, lv2) and feats2[0] is None
     for f, fr in zip(feats, feats_r):
         close(f.permute(0, 3, 1, 2), fr, tol=1e-4)
+
+
+@pytest.mark.parametrize("B,C_in,C_out,H", [(64, 128, 128, 32), (64, 256, 256, 16), (256, 512, 512, 8), (64, 64, 128, 32)])
+def test_f16x2_training_convs(dev, B, C_in, C_out, H):
+    """The training paths' 3x3 s1 convs on the f16x2 kernel: forward with the measured input range (fl_absmax) and the input
+    gradient as the mirror convolution (taps flipped, channel roles swapped) vs torch fp64. Bar: 1e-5 of the output max
+    (the kernel's error class, test_f16x2_conv_is_fp32_equivalent)."""
+    import types
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import engine, engine_bwd
+    conv = torch.nn.Conv2d(C_in, C_out, 3, 1, 1).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(C_out, C_in, 3, 3, seed=1, scale=0.05))
+        conv.bias.copy_(rnd(C_out, seed=2))
+    pk = engine.PackCache()
+    x = rnd(B, C_in, H, H, seed=3, scale=3.0)
+    dy = rnd(B, C_out, H, H, seed=4, scale=1e-3)              # gradients are small and badly scaled
+    dy[:, :, 0, 0] *= 300.0
+    xh, dyh = nhwc(x).to(dev), nhwc(dy).to(dev)
+    assert float(ops.absmax(xh)) == float(x.abs().max())
+    assert engine_bwd._h2_ok(xh, C_out) and engine_bwd._h2_ok(dyh, C_in) == (C_in % 128 == 0)   # else: the bf16x3 dgrad
+    y = engine_bwd.conv3_fwd_act(xh, conv, pk, ops.ACT_RELU)
+    ref = F.relu(F.conv2d(x.double(), conv.weight.detach().cpu().double(), conv.bias.detach().cpu().double(), 1, 1))
+    close(nchw(y), ref, 1e-5)
+    dx = engine_bwd.conv3_dgrad(dyh, conv, (H, H), pk)
+    dref = F.conv_transpose2d(dy.double(), conv.weight.detach().cpu().double(), None, 1, 1)
+    a, b = nchw(dx).cpu().double(), dref
+    assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+    # the pack follows the weight version
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    dx2 = engine_bwd.conv3_dgrad(dyh, conv, (H, H), pk)
+    assert (nchw(dx2).cpu().double() - 2 * b).abs().max().item() <= 2e-5 * b.abs().max().item()
