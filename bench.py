@@ -470,7 +470,12 @@ def main():
     # the denoiser as persistent phase programs (default) needs the whole device: encoder graph -> programs on one stream.
     # FL_TRAIN_PROGRAM=0 restores the multi-kernel denoiser, which runs as a second stream next to the encoder of the next batch
     overlap = use_graph and not a.no_overlap and not tr.persistent
-    if overlap:
+    dp_overlap = use_graph and tr.persistent and world > 1 and not a.no_overlap   # all-reduce under the next batch's encoder
+    if dp_overlap:
+        tr.capture_overlapped(sdata, slabels)
+        tr.prime_overlapped(batches[0], labels[0])
+        log("hipGraphs captured (all-reduce of step k under the encoder of batch k+1)")
+    elif overlap:
         tr.capture_pipelined(sdata, slabels)
         tr.prime_pipeline(batches[0], labels[0])
         log("hipGraphs captured (encoder || denoiser pipeline)")
@@ -479,6 +484,8 @@ def main():
         log("hipGraph captured")
 
     def one_step(i):
+        if dp_overlap:
+            return tr.replay_overlapped(batches[(i + 1) % nb], labels[(i + 1) % nb])
         if overlap:  # step i trains on batch i (already encoded) while batch i+1 is being encoded
             return tr.replay_pipelined(batches[(i + 1) % nb], labels[(i + 1) % nb])
         if use_graph:
@@ -539,6 +546,7 @@ def main():
             "hipgraph": use_graph,
             "encoder_denoiser_overlap": overlap,
             "denoiser_persistent_programs": bool(tr.persistent),
+            "allreduce_under_next_encoder": dp_overlap,
             "loss": final_loss,
             "gemm_math": gemm_math_note,
         },

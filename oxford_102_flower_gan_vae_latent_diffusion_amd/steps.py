@@ -267,6 +267,54 @@ class DDPMTrainer:
         self.g2.replay()
         return self.loss
 
+    # ---- data-parallel step with the gradient all-reduce hidden behind the NEXT batch's encoder ---------------
+    # The persistent programs need the device to themselves, the frozen encoder does not, and it does not depend on
+    # the update either (v2:1257-1259): [denoiser fwd/bwd program (k)] -> all-reduce (k) on RCCL's stream, WHILE the
+    # encoder graph of batch k+1 runs on the compute stream -> [optimizer program (k)]. Same arithmetic and update order
+    # as step(); one collective per step, off the critical path instead of serialised between two launches.
+    def capture_overlapped(self, data, labels):
+        dev = self.dev
+        self.static_data, self.static_labels = data, labels
+        for _ in range(2):
+            self.step(data, labels)
+        torch.cuda.synchronize(dev)
+        B, L = data.shape[0], self.ae.latent_dim
+        self.z_next = torch.zeros(B, L, device=dev)
+        self.z_in = torch.zeros(B, L, device=dev)
+        self.lab_next, self.lab_in = labels.clone(), labels.clone()
+        self.gE = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gE):
+            self.z_next.copy_(self.encode(self.static_data))
+        self.gU = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gU, pool=self.gE.pool()):
+            self.fwd_bwd(self.z_in, self.lab_in)
+        self.gO = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gO, pool=self.gE.pool()):
+            self.update()
+
+    def prime_overlapped(self, data, labels):
+        """encode the first batch (before the timed region)."""
+        self.static_data.copy_(data)
+        self.gE.replay()
+        self.lab_next.copy_(labels)
+
+    def replay_overlapped(self, next_data, next_labels):
+        """one step on the latents encoded by the previous call; `next_data` is encoded under the all-reduce."""
+        self.z_in.copy_(self.z_next)
+        self.lab_in.copy_(self.lab_next)
+        self.gU.replay()
+        work = None
+        if self.world > 1:
+            import torch.distributed as dist
+            work = dist.all_reduce(self.fp.grad[:self.fp.n_active], group=self.pg, async_op=True)
+        self.static_data.copy_(next_data)
+        self.gE.replay()
+        self.lab_next.copy_(next_labels)
+        if work is not None:
+            work.wait()      # the compute stream waits for the collective; the host does not block
+        self.gO.replay()
+        return self.loss
+
     # ---- cross-step software pipeline -------------------------------------------------------------------
     # The frozen encoder of batch k+1 does not depend on the denoiser update of batch k (v2:1257-1259 runs under
     # no_grad on a module that is never trained here), so the two phases run concurrently: stream E replays the

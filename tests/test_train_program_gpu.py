@@ -289,3 +289,44 @@ def test_program_step_graph_capture_and_replay(dev):
     assert outs[0][0] == outs[1][0]
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_overlapped_dp_schedule_equals_plain_steps(dev):
+    """capture_overlapped / replay_overlapped (the N > 1 bench schedule: encoder of batch k+1 between the denoiser program and
+    the optimizer program of batch k) on one rank == plain step() on the same batches, bit for bit."""
+    B, n = 32, 4
+    g = torch.Generator().manual_seed(7)
+    data = [(torch.rand(B, 3, 64, 64, generator=g) * 2 - 1).to(dev) for _ in range(n + 1)]
+    labels = [torch.randint(0, 102, (B,), generator=g).to(dev) for _ in range(n + 1)]
+
+    def make():
+        ae = _seeded(M.SimpleAutoencoder(), 42).to(dev).eval()
+        un = _seeded(M.ConditionalUNet(), 44).to(dev).train()
+        tr = steps.DDPMTrainer(ae, un, lr=1e-3, persistent=True)
+        reseed(ae, un, tr)       # before any capture: the Philox seed is a kernel argument baked into the graphs
+        return ae, un, tr
+
+    def reseed(ae, un, tr):
+        for r, s_ in ((ae.rng, 1), (un.rng, 2), (tr.diffusion.rng, 3)):
+            r.manual_seed(s_)
+
+    ae, un, tr = make()
+    reseed(ae, un, tr)
+    la = [float(tr.step(data[i], labels[i])) for i in range(n)]
+    pa = tr.fp.flat.clone()
+    ae, un, tr = make()
+    sd0 = {k: v.clone() for k, v in un.state_dict().items()}
+    tr.capture_overlapped(data[0].clone(), labels[0].clone())
+    un.load_state_dict(sd0)                      # capture ran warm-up steps: restore weights, optimizer and RNG state
+    tr.opt.m.zero_(); tr.opt.v.zero_(); tr.opt.step_count.zero_()
+    reseed(ae, un, tr)
+    # plain steps draw reparam noise (ae.rng) then t / eps / masks per step, in that order per batch: the overlapped schedule
+    # encodes batch k+1 before step k's draws only on ae.rng (its own stream), so every stream sees the same sequence
+    tr.prime_overlapped(data[0], labels[0])
+    lb = []
+    for i in range(n):
+        l = tr.replay_overlapped(data[i + 1], labels[i + 1])
+        torch.cuda.synchronize()
+        lb.append(float(l))
+    assert lb == la
+    assert torch.equal(tr.fp.flat, pa)
