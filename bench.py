@@ -166,6 +166,21 @@ def _wall(fn, iters, warm=3):
     return (time.perf_counter() - t0) / iters
 
 
+def library_gemm_tflops(dev, n=8192, iters=20):
+    """the vendor library's plain bf16 GEMM (torch.mm -> hipBLASLt), n^3: a reference point for the matrix pipe, never part
+    of the product path"""
+    a = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        torch.mm(a, b)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        torch.mm(a, b)
+    torch.cuda.synchronize(dev)
+    return 2.0 * n ** 3 * iters / (time.perf_counter() - t0) / 1e12
+
+
 def secondary_unet_fwd(dev):
     """north-star target: ConditionalUNet forward at batch 256 (4.161 GFLOP of record), as one persistent program launch
     (csrc/program.hip: v_mfma_f32_32x32x2_f32, exact fp32) and as the multi-kernel hipGraph."""
@@ -569,6 +584,12 @@ def main():
                               if r["pp"] else "fp32 dense MFMA peak",
                 "achieved_over_fp32_mfma_peak": r["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                 "f16x2_vs_fp32_mfma_max_rel_diff": f16x2_vs_fp32_mfma(dev),
+                # context for `frac`: what the matrix pipe sustains on this box under a real load. The vendor library's plain
+                # bf16 GEMM (8192^3, measured here) is the practical ceiling of any MFMA kernel that also moves data: the
+                # shader clock sits at ~1.85-1.9 GHz under it and under the conv kernel (profiles/r02_conv_power_probe.txt),
+                # not at the 2.4 GHz the data-sheet peak assumes
+                "issued_16bit_mfma_tflops": r["tflops"] * r["pp"] if r["pp"] else None,
+                "library_bf16_gemm_8192_tflops": library_gemm_tflops(dev),
                 "traffic": PMC_TRAFFIC.get(dom) if B == 256 else None,
                 "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r02_conv_h2_pmc.md" if PMC_TRAFFIC.get(dom) else None,
                 "algorithmic_bytes_per_launch": r["bytes_per_launch"],

@@ -229,17 +229,27 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
     f16x8_t a[2][2];  // [tm][plane]
     f16x8_t b[2][2];  // [tn][piece]
   };
+  // -DFL_H2_ABLATE=n: timing-only builds with WRONG results (tools/conv_h2_bench.py): 1 = no B fragment reads after the
+  // first tap, 2 = no A fragment reads after the first tap, 3 = neither
+#ifndef FL_H2_ABLATE
+#define FL_H2_ABLATE 0
+#endif
+  bool abl_first = true;
   auto frag_load = [&](Frags& f, int abuf, int tapoff, int slot) {
     const char* A = smem + abuf * ABUF_B + tapoff;
     const char* Bp = smem + bfrag + slot * SLOT_B;
+    if ((FL_H2_ABLATE & 1) == 0 || abl_first) {
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+      for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-      for (int p = 0; p < 2; ++p) f.b[tn][p] = *reinterpret_cast<const f16x8_t*>(Bp + tn * 2048 + p * 1024);
+        for (int p = 0; p < 2; ++p) f.b[tn][p] = *reinterpret_cast<const f16x8_t*>(Bp + tn * 2048 + p * 1024);
+    }
+    if ((FL_H2_ABLATE & 2) == 0 || abl_first) {
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+      for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-      for (int p = 0; p < 2; ++p) f.a[tm][p] = *reinterpret_cast<const f16x8_t*>(A + abase[tm] + p * PLANE_B);
+        for (int p = 0; p < 2; ++p) f.a[tm][p] = *reinterpret_cast<const f16x8_t*>(A + abase[tm] + p * PLANE_B);
+    }
   };
 
   f32x16 acc[2][2];
@@ -275,6 +285,8 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
   asm volatile("" ::: "memory");
   Frags fA, fB;
   frag_load(fA, 0, 0, 0);
+  fB = fA;
+  abl_first = false;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
