@@ -135,6 +135,15 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
 size_t fl_pack_weight_f16x2_bytes(int N, int K);
 int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, fl_stream_t stream);
 int fl_conv2d_fwd_f16x2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+/* nn.Linear forward with a long reduction in f16x2 split math (the frozen encoder's heads, v2:210-221: K = 32768): y = x W^T +
+ * bias with W packed by fl_pack_weight_f16x2 ([N][K], layout 0) and x scaled as for the convs (x_amax / x_exp). Split-K over
+ * as many blocks as fill the chip (slabs in `ws`), then one reduce pass that also adds the bias. y is written as N / n_block
+ * consecutive [M][n_block] matrices (n_block = N: plain row-major) - two concatenated heads come out as two tensors.
+ * M % 256 == 0, N % 128 == 0, K % 32 == 0 (fl_linear_fwd_f16x2_applicable). */
+int fl_linear_fwd_f16x2_applicable(int M, int N, int K);
+size_t fl_linear_fwd_f16x2_workspace_bytes(int M, int N, int K);
+int fl_linear_fwd_f16x2(const float* x, int lda, const void* wpack, const float* bias, float* y, int n_block, int M, int N, int K,
+                        const float* x_amax, int x_exp, void* ws, size_t ws_bytes, fl_stream_t stream);
 /* out[0] = max|x| over n floats: x_amax of fl_conv2d_fwd_f16x2 for inputs whose producer keeps no bound (the training paths'
  * activations and gradients, v2:1060-1134). */
 int fl_absmax(const float* x, int64_t n, float* out, fl_stream_t stream);

@@ -738,6 +738,165 @@ int h2_bm(int W, int Cin, bool pre, long long M, int Cout) {
   return bm;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// nn.Linear with a huge reduction in f16x2 split math: the frozen encoder's two heads (v2:210-221: 32768 -> 512 each, batch
+// 256: 17 GFLOP that the generic split-K kernel ran at 91 TFLOP/s). y[M, N] = x[M, K] W[N, K]^T as split-K slabs:
+// block = 256 rows x 128 columns x (K / splits), 8 waves of 64 x 64 like the conv kernels, 12 MFMAs per wave and 16-k group.
+// Nothing here is reused across taps, so there is no halo and no ring: the weight fragments (packed once, frozen) come
+// straight from global memory into the MFMA operand registers (one coalesced 1-KB load per fragment; the four waves of a
+// column hit the same lines in L1), the activations go global -> registers -> split -> LDS two 16-k groups at a time, both
+// two chunks ahead of their use. Plain loads and __syncthreads only: hipcc counts the waits.
+struct LinH2Args {
+  const float* x;
+  const char* wpack;
+  float* slabs;              // [splits][M][N]
+  const unsigned* a_amax;
+  int a_exp, lda, M, N, K, tiles_n, splits, chunks;  // chunks (of 32 k) per split
+};
+
+constexpr int LIN_PXB = 48, LIN_PLANE_B = 256 * LIN_PXB, LIN_GROUP_B = 2 * LIN_PLANE_B, LIN_ABUF_B = 2 * LIN_GROUP_B;
+constexpr int LIN_LDS_B = 2 * LIN_ABUF_B;
+
+__global__ __launch_bounds__(512) void linear_h2_kernel(const LinH2Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1, li = lane & 31, lh = lane >> 5;
+  const int sp = blockIdx.x % g.splits, rest = blockIdx.x / g.splits;
+  const int tile_n0 = (rest % g.tiles_n) * 128, tile_m0 = (rest / g.tiles_n) * 256;
+  const int ea = g.a_amax ? scale_exp_from_amax(*g.a_amax) : g.a_exp;
+  const float sa = __uint_as_float((unsigned)(ea + 127) << 23);
+  const float out_scale = reinterpret_cast<const float*>(g.wpack)[1] * __uint_as_float((unsigned)(127 - ea) << 23);
+  const int nt32 = g.N >> 5, nch = g.chunks;
+  const long long grp0 = (long long)sp * nch * 2;  // first 16-k group of this split
+
+  // A staging items: i = tid + 512 j -> row i >> 3, float4 q = i & 7 of the chunk's 32 floats (group q >> 2, c4 = q & 3)
+  const float* asrc[4];
+  int adst[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 512 * j, row = i >> 3, q = i & 7;
+    asrc[j] = g.x + (size_t)(tile_m0 + row) * g.lda + grp0 * 16 + q * 4;
+    adst[j] = (q >> 2) * LIN_GROUP_B + row * LIN_PXB + (q & 3) * 8;
+  }
+  // B fragments of this wave: [group][32-column tile tn][piece] x 1 KB, lane * 16 inside
+  const char* bsrc = g.wpack + H2_HDR + (((size_t)grp0 * nt32 + (tile_n0 >> 5) + wc * 2) * 2) * 1024 + lane * 16;
+  const size_t bgrp = (size_t)nt32 * 2 * 1024;  // bytes from one group's fragments to the next group's
+  const int afrag = (wr * 64 + li) * LIN_PXB + 16 * lh;  // + gi * GROUP_B + p * PLANE_B + tm * 32 * PXB
+
+  struct BF { f16x8_t b[2][2][2]; };  // [group of the chunk][tn][piece]
+  auto load_a = [&](f32x4v (&st)[4], int c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st[j] = *reinterpret_cast<const f32x4v*>(asrc[j] + (size_t)c * 32);
+  };
+  auto load_b = [&](BF& f, int c) {
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          f.b[gi][tn][p] = *reinterpret_cast<const f16x8_t*>(bsrc + (size_t)(2 * c + gi) * bgrp + (tn * 2 + p) * 1024);
+  };
+  auto store_a = [&](const f32x4v (&st)[4], int buf) {
+    char* dst = smem + buf * LIN_ABUF_B;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x4_t h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float X = st[j][e] * sa;
+        const _Float16 hh = (_Float16)X;
+        h[e] = hh;
+        l[e] = (_Float16)(X - (float)hh);
+      }
+      *reinterpret_cast<f16x4_t*>(dst + adst[j]) = h;
+      *reinterpret_cast<f16x4_t*>(dst + LIN_PLANE_B + adst[j]) = l;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  auto compute = [&](const BF& f, int buf) {
+    const char* A = smem + buf * LIN_ABUF_B + afrag;
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      f16x8_t a[2][2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          a[tm][p] = *reinterpret_cast<const f16x8_t*>(A + gi * LIN_GROUP_B + p * LIN_PLANE_B + tm * 32 * LIN_PXB);
+#define FL_PIECE(pa, pb)                                                                              \
+      _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) \
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm][pa], f.b[gi][tn][pb], acc[tm][tn], 0, 0, 0);
+      FL_PIECE(1, 0) FL_PIECE(0, 1) FL_PIECE(0, 0)  // l*h, h*l, h*h: smallest terms first
+#undef FL_PIECE
+    }
+  };
+
+  // software pipeline over chunks: A of chunk c+2 and B of chunk c+2 are requested while chunk c is contracted
+  f32x4v sa0[4], sa1[4];
+  BF b0, b1, b2;
+  load_a(sa0, 0);
+  load_b(b0, 0);
+  if (nch > 1) { load_a(sa1, 1); load_b(b1, 1); }
+  store_a(sa0, 0);
+  __syncthreads();
+  // three-way rotation of the B registers, two-way of the A staging registers and LDS buffers: period 6
+#define FL_LIN_STEP(c, BC, BN2, SN1, SN2)                                   \
+  do {                                                                      \
+    if ((c) < nch) { /* block-uniform */                                    \
+      if ((c) + 2 < nch) { load_a(SN2, (c) + 2); load_b(BN2, (c) + 2); }    \
+      if ((c) + 1 < nch) store_a(SN1, ((c) + 1) & 1);                       \
+      compute(BC, (c) & 1);                                                 \
+      __syncthreads();                                                      \
+    }                                                                       \
+  } while (0)
+  for (int c = 0; c < nch; c += 6) {
+    FL_LIN_STEP(c + 0, b0, b2, sa1, sa0);
+    FL_LIN_STEP(c + 1, b1, b0, sa0, sa1);
+    FL_LIN_STEP(c + 2, b2, b1, sa1, sa0);
+    FL_LIN_STEP(c + 3, b0, b2, sa0, sa1);
+    FL_LIN_STEP(c + 4, b1, b0, sa1, sa0);
+    FL_LIN_STEP(c + 5, b2, b1, sa0, sa1);
+  }
+#undef FL_LIN_STEP
+
+  // slab store (C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+  float* slab = g.slabs + (size_t)sp * g.M * g.N;
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = tile_m0 + wr * 64 + tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      float* yrow = slab + (size_t)m * g.N + tile_n0 + wc * 64 + li;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) yrow[tn * 32] = acc[tm][tn][e] * out_scale;
+    }
+  }
+}
+
+// y[(col / nb)][row][col % nb] = bias[col] + sum over the split-K slabs (nb = N: plain row-major y)
+__global__ void linear_h2_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ y,
+                                        int M, int N, int nb, int splits) {
+  const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 * 4 >= (long long)M * N) return;
+  const int row = (int)(i4 * 4 / N), col = (int)(i4 * 4 - (long long)row * N);
+  float4 a = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* p = slabs + i4 * 4;
+  for (int s = 0; s < splits; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)s * M * N);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  *reinterpret_cast<float4*>(y + (size_t)(col / nb) * M * nb + (size_t)row * nb + col % nb) = a;
+}
+
 }  // namespace
 
 namespace fl {
@@ -860,6 +1019,50 @@ int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, fl
   FL_REQUIRE(layout == 0 || (layout == 1 && K % 128 == 0), "fl_pack_weight_f16x2: layout %d (0 = 16-k groups, 1 = 4x4 tap pairs, K = 16 Cin, Cin %% 8 == 0)", layout);
   FL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0, "fl_pack_weight_f16x2: 16-byte alignment");
   return fl::pack_weight_f16x2(w, out, N, K, layout, reinterpret_cast<hipStream_t>(stream));
+}
+
+// splits: the largest divisor of the chunk count (32 k each) that keeps the grid within one block per CU
+static int lin_h2_splits(int M, int N, int K) {
+  const int tiles = (M / 256) * (N / 128), nchunks = K / 32;
+  int best = 0;
+  for (int s = 1; s <= nchunks; ++s) {
+    if (nchunks % s) continue;
+    if (tiles * s <= 256 || best == 0) best = s;
+  }
+  return best;
+}
+
+int fl_linear_fwd_f16x2_applicable(int M, int N, int K) {
+  return M > 0 && M % 256 == 0 && N % 128 == 0 && K % 32 == 0 && lin_h2_splits(M, N, K) > 0;
+}
+
+size_t fl_linear_fwd_f16x2_workspace_bytes(int M, int N, int K) {
+  if (!fl_linear_fwd_f16x2_applicable(M, N, K)) return 0;
+  return (size_t)lin_h2_splits(M, N, K) * M * N * sizeof(float);
+}
+
+// y = x W^T + bias, W packed by fl_pack_weight_f16x2 ([N][K], layout 0). y is written as N / n_block consecutive [M][n_block]
+// matrices (n_block = N: one row-major [M][N]); n_block % 4 == 0.
+int fl_linear_fwd_f16x2(const float* x, int lda, const void* wpack, const float* bias, float* y, int n_block, int M, int N, int K,
+                        const float* x_amax, int x_exp, void* ws, size_t ws_bytes, fl_stream_t stream) {
+  FL_REQUIRE(x && wpack && y && fl_linear_fwd_f16x2_applicable(M, N, K), "fl_linear_fwd_f16x2: M=%d (mult. of 256) N=%d (mult. of 128) K=%d", M, N, K);
+  FL_REQUIRE(lda >= K && lda % 4 == 0 && n_block > 0 && N % n_block == 0 && n_block % 4 == 0, "fl_linear_fwd_f16x2: lda=%d n_block=%d", lda, n_block);
+  FL_REQUIRE(ws && ws_bytes >= fl_linear_fwd_f16x2_workspace_bytes(M, N, K), "fl_linear_fwd_f16x2: workspace too small");
+  FL_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpack) | reinterpret_cast<uintptr_t>(y) |
+               reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0, "fl_linear_fwd_f16x2: 16-byte alignment");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  LinH2Args g;
+  g.x = x; g.wpack = reinterpret_cast<const char*>(wpack); g.slabs = reinterpret_cast<float*>(ws);
+  g.a_amax = reinterpret_cast<const unsigned*>(x_amax); g.a_exp = x_exp; g.lda = lda; g.M = M; g.N = N; g.K = K;
+  g.tiles_n = N / 128; g.splits = lin_h2_splits(M, N, K); g.chunks = K / 32 / g.splits;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LIN_LDS_B);
+  });
+  hipLaunchKernelGGL(linear_h2_kernel, dim3((M / 256) * g.tiles_n * g.splits), dim3(512), LIN_LDS_B, s, g);
+  const long long n4 = (long long)M * N / 4;
+  hipLaunchKernelGGL(linear_h2_reduce_kernel, dim3(fl::cdiv(n4, 256)), dim3(256), 0, s, g.slabs, bias, y, M, N, n_block, g.splits);
+  return fl::check_launch("linear_h2_kernel");
 }
 
 // out[0] = max|x| (a device float; 0 for n == 0): the range information fl_conv2d_fwd_f16x2 takes as x_amax when the

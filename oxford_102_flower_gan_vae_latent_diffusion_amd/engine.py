@@ -190,6 +190,24 @@ def encoder_infer(enc, x, want_feats=True):
         w = fc[0].weight
         return pk.get(("fc_nhwc", id(fc)), [w], lambda: ops.nchw_to_nhwc(w.detach().view(-1, Ch, Hh, Wh)).view(w.shape[0], -1))
 
+    N1 = enc.fc_mu[0].weight.shape[0]
+    if (USE_F16X2 and bound is not None and ops.get_gemm_math() == "split" and enc.fc_logvar[0].weight.shape[0] == N1
+            and ops.linear_f16x2_ok(B, 2 * N1, flat.shape[1])):
+        # both heads' first Linear (2 x 512 x 32768, the longest reduction of the step) as ONE f16x2 split-K GEMM on the
+        # concatenated, NHWC-permuted, pre-packed weight; x range = the bound of the last ResidualBlock's output
+        def make():
+            w = torch.cat([perm(enc.fc_mu), perm(enc.fc_logvar)], 0).contiguous()
+            b = torch.cat([enc.fc_mu[0].bias.detach(), enc.fc_logvar[0].bias.detach()]).contiguous()
+            return ops.pack_weight_f16x2(w), b
+
+        wh, bcat = pk.get(("fc_heads_h2",), [enc.fc_mu[0].weight, enc.fc_logvar[0].weight, enc.fc_mu[0].bias,
+                                              enc.fc_logvar[0].bias], make)
+        g2 = ops.linear_fwd_f16x2(flat, wh, 2 * N1, bcat, n_block=N1, x_amax=bound)
+        outs = []
+        for hi, fc in enumerate((enc.fc_mu, enc.fc_logvar)):
+            gh, _, _ = ops.layernorm_fwd(g2[hi], _d(fc[1].weight), _d(fc[1].bias), eps=fc[1].eps, act=SW, save=False)
+            outs.append(ops.linear(gh, _d(fc[3].weight), _d(fc[3].bias)))
+        return outs[0], outs[1], feats
     return _head(enc.fc_mu, flat, perm(enc.fc_mu)), _head(enc.fc_logvar, flat, perm(enc.fc_logvar)), feats
 
 

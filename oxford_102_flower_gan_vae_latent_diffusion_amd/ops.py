@@ -306,6 +306,21 @@ def conv2d_fwd_f16x2(x, wpack, geom, bias, stride=1, pad=1, act=ACT_NONE, act_pa
     return y, (scale, shift, mean, rstd)
 
 
+def linear_f16x2_ok(M, N, K):
+    return bool(_lib.load().fl_linear_fwd_f16x2_applicable(int(M), int(N), int(K)))
+
+
+def linear_fwd_f16x2(x, wpack, N, bias=None, n_block=None, x_amax=None, x_exp=6):
+    """x (M, K) @ W^T + bias with W (N, K) packed by pack_weight_f16x2; returns (N / n_block, M, n_block) (n_block = N: (M, N))."""
+    _chk(x, bias, x_amax)
+    M, K = x.shape
+    nb = N if n_block is None else n_block
+    y = new((N // nb, M, nb) if nb != N else (M, N), x)
+    wsp, wsn = _ws(_lib.load().fl_linear_fwd_f16x2_workspace_bytes(M, N, K), x)
+    _lib.call("fl_linear_fwd_f16x2", _p(x), K, _p(wpack), _p(bias), _p(y), nb, M, N, K, _p(x_amax), int(x_exp), wsp, wsn, _stream())
+    return y
+
+
 def absmax(x):
     """(1,) device float = max|x| (fl_absmax): range information of the f16x2 convs for training activations / gradients."""
     _chk(x)

@@ -750,3 +750,27 @@ def test_f16x2_training_convs(dev, B, C_in, C_out, H):
         conv.weight.mul_(2.0)
     dx2 = engine_bwd.conv3_dgrad(dyh, conv, (H, H), pk)
     assert (nchw(dx2).cpu().double() - 2 * b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,nb", [(256, 1024, 32768, 512), (256, 128, 192, 128), (512, 256, 64, 64), (256, 128, 32, 128)])
+def test_f16x2_linear_long_reduction(dev, M, N, K, nb):
+    """fl_linear_fwd_f16x2 (the frozen encoder heads' 32768-long contraction, v2:210-221) vs fp64: split-K slabs + reduce,
+    concatenated heads written as separate matrices, one- and two-chunk splits. Bar: 3e-6 of the output max at K = 32768
+    (the conv kernels' error class), and it must beat-or-match the native fp32 MFMA GEMM's error."""
+    x = rnd(M, K, seed=1, scale=1.5)
+    x = x * torch.sigmoid(x)
+    w = rnd(N, K, seed=2, scale=(1.0 / K) ** 0.5)
+    b = rnd(N, seed=3)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    assert ops.linear_f16x2_ok(M, N, K)
+    wh = ops.pack_weight_f16x2(wd)
+    y = ops.linear_fwd_f16x2(xd, wh, N, bd, n_block=nb, x_amax=ops.absmax(xd))
+    ref = x.double() @ w.double().t() + b.double()
+    if nb != N:
+        assert y.shape == (N // nb, M, nb)
+        y = torch.cat([y[i] for i in range(N // nb)], 1)
+    err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 3e-6, err
+    y2 = ops.linear_fwd_f16x2(xd, wh, N, bd, n_block=N, x_amax=ops.absmax(xd))
+    assert torch.equal(y2, y.to(dev)) if nb != N else True     # deterministic, layout-independent
+    assert not ops.linear_f16x2_ok(100, N, K) and not ops.linear_f16x2_ok(M, 96, K)
