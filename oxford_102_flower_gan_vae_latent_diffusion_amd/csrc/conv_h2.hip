@@ -743,10 +743,9 @@ int h2_bm(int W, int Cin, bool pre, long long M, int Cout) {
 // nn.Linear with a huge reduction in f16x2 split math: the frozen encoder's two heads (v2:210-221: 32768 -> 512 each, batch
 // 256: 17 GFLOP that the generic split-K kernel ran at 91 TFLOP/s). y[M, N] = x[M, K] W[N, K]^T as split-K slabs:
 // block = 256 rows x 128 columns x (K / splits), 8 waves of 64 x 64 like the conv kernels, 12 MFMAs per wave and 16-k group.
-// Nothing here is reused across taps, so there is no halo and no ring: the weight fragments (packed once, frozen) come
-// straight from global memory into the MFMA operand registers (one coalesced 1-KB load per fragment; the four waves of a
-// column hit the same lines in L1), the activations go global -> registers -> split -> LDS two 16-k groups at a time, both
-// two chunks ahead of their use. Plain loads and __syncthreads only: hipcc counts the waits.
+// Nothing here is reused across taps, so there is no halo and no DMA ring: the weight fragments (packed once, frozen; the
+// block's 16 KB per 32 k) and the activations (split on the way) go global -> registers -> LDS one chunk of two 16-k groups
+// at a time, requested three chunks ahead of their use. Plain loads and __syncthreads only: hipcc counts the waits.
 struct LinH2Args {
   const float* x;
   const char* wpack;
@@ -756,7 +755,8 @@ struct LinH2Args {
 };
 
 constexpr int LIN_PXB = 48, LIN_PLANE_B = 256 * LIN_PXB, LIN_GROUP_B = 2 * LIN_PLANE_B, LIN_ABUF_B = 2 * LIN_GROUP_B;
-constexpr int LIN_LDS_B = 2 * LIN_ABUF_B;
+constexpr int LIN_BBUF_B = 2 * 8192, LIN_BOFF = 2 * LIN_ABUF_B;  // B: [group][tile 0..3][piece][lane] x 16 B per buffer
+constexpr int LIN_LDS_B = LIN_BOFF + 2 * LIN_BBUF_B;
 
 __global__ __launch_bounds__(512) void linear_h2_kernel(const LinH2Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -779,33 +779,29 @@ __global__ __launch_bounds__(512) void linear_h2_kernel(const LinH2Args g) {
     asrc[j] = g.x + (size_t)(tile_m0 + row) * g.lda + grp0 * 16 + q * 4;
     adst[j] = (q >> 2) * LIN_GROUP_B + row * LIN_PXB + (q & 3) * 8;
   }
-  // B fragments of this wave: [group][32-column tile tn][piece] x 1 KB, lane * 16 inside
-  const char* bsrc = g.wpack + H2_HDR + (((size_t)grp0 * nt32 + (tile_n0 >> 5) + wc * 2) * 2) * 1024 + lane * 16;
+  // B staging: the block's fragments of a chunk are 2 groups x 8 KB ([tile 0..3][piece][lane] x 16 B, contiguous in the
+  // pack); thread tid moves 16 bytes of each group. Through LDS, so that the four waves of a column do not each pull their
+  // own copy through the L1 (64 KB per chunk and CU at 64 B/clk was the bound of the first version: 74 us)
+  const char* bsrc = g.wpack + H2_HDR + (((size_t)grp0 * nt32 + (tile_n0 >> 5)) * 2) * 1024 + tid * 16;
   const size_t bgrp = (size_t)nt32 * 2 * 1024;  // bytes from one group's fragments to the next group's
   const int afrag = (wr * 64 + li) * LIN_PXB + 16 * lh;  // + gi * GROUP_B + p * PLANE_B + tm * 32 * PXB
+  const int bfrag = LIN_BOFF + wc * 4096 + lane * 16;    // + buf * BBUF_B + gi * 8192 + tn * 2048 + p * 1024
 
-  struct BF { f16x8_t b[2][2][2]; };  // [group of the chunk][tn][piece]
-  auto load_a = [&](f32x4v (&st)[4], int c) {
+  struct Stg { f32x4v a[4], b[2]; };
+  auto load = [&](Stg& st, int c) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st[j] = *reinterpret_cast<const f32x4v*>(asrc[j] + (size_t)c * 32);
+    for (int j = 0; j < 4; ++j) st.a[j] = *reinterpret_cast<const f32x4v*>(asrc[j] + (size_t)c * 32);
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) st.b[gi] = *reinterpret_cast<const f32x4v*>(bsrc + (size_t)(2 * c + gi) * bgrp);
   };
-  auto load_b = [&](BF& f, int c) {
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-          f.b[gi][tn][p] = *reinterpret_cast<const f16x8_t*>(bsrc + (size_t)(2 * c + gi) * bgrp + (tn * 2 + p) * 1024);
-  };
-  auto store_a = [&](const f32x4v (&st)[4], int buf) {
+  auto store = [&](const Stg& st, int buf) {
     char* dst = smem + buf * LIN_ABUF_B;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f16x4_t h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float X = st[j][e] * sa;
+        const float X = st.a[j][e] * sa;
         const _Float16 hh = (_Float16)X;
         h[e] = hh;
         l[e] = (_Float16)(X - (float)hh);
@@ -813,6 +809,8 @@ __global__ __launch_bounds__(512) void linear_h2_kernel(const LinH2Args g) {
       *reinterpret_cast<f16x4_t*>(dst + adst[j]) = h;
       *reinterpret_cast<f16x4_t*>(dst + LIN_PLANE_B + adst[j]) = l;
     }
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) *reinterpret_cast<f32x4v*>(smem + LIN_BOFF + buf * LIN_BBUF_B + gi * 8192 + tid * 16) = st.b[gi];
   };
 
   f32x16 acc[2][2];
@@ -822,49 +820,49 @@ __global__ __launch_bounds__(512) void linear_h2_kernel(const LinH2Args g) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-  auto compute = [&](const BF& f, int buf) {
+  auto compute = [&](int buf) {
     const char* A = smem + buf * LIN_ABUF_B + afrag;
+    const char* Bp = smem + bfrag + buf * LIN_BBUF_B;
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
-      f16x8_t a[2][2];
+      f16x8_t a[2][2], b[2][2];
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-          a[tm][p] = *reinterpret_cast<const f16x8_t*>(A + gi * LIN_GROUP_B + p * LIN_PLANE_B + tm * 32 * LIN_PXB);
+        for (int p = 0; p < 2; ++p) {
+          a[t][p] = *reinterpret_cast<const f16x8_t*>(A + gi * LIN_GROUP_B + p * LIN_PLANE_B + t * 32 * LIN_PXB);
+          b[t][p] = *reinterpret_cast<const f16x8_t*>(Bp + gi * 8192 + t * 2048 + p * 1024);
+        }
 #define FL_PIECE(pa, pb)                                                                              \
       _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) \
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm][pa], f.b[gi][tn][pb], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm][pa], b[tn][pb], acc[tm][tn], 0, 0, 0);
       FL_PIECE(1, 0) FL_PIECE(0, 1) FL_PIECE(0, 0)  // l*h, h*l, h*h: smallest terms first
 #undef FL_PIECE
     }
   };
 
-  // software pipeline over chunks: A of chunk c+2 and B of chunk c+2 are requested while chunk c is contracted
-  f32x4v sa0[4], sa1[4];
-  BF b0, b1, b2;
-  load_a(sa0, 0);
-  load_b(b0, 0);
-  if (nch > 1) { load_a(sa1, 1); load_b(b1, 1); }
-  store_a(sa0, 0);
+  // software pipeline over chunks: chunk c+3 is requested, chunk c+1 parked in LDS, chunk c contracted; three staging
+  // register sets in rotation, two LDS buffers (period 6)
+  Stg s0, s1, s2;
+  load(s0, 0);
+  if (nch > 1) load(s1, 1);
+  if (nch > 2) load(s2, 2);
+  store(s0, 0);
   __syncthreads();
-  // three-way rotation of the B registers, two-way of the A staging registers and LDS buffers: period 6
-#define FL_LIN_STEP(c, BC, BN2, SN1, SN2)                                   \
+#define FL_LIN_STEP(c, SNEXT, SFREE)                                        \
   do {                                                                      \
     if ((c) < nch) { /* block-uniform */                                    \
-      if ((c) + 2 < nch) { load_a(SN2, (c) + 2); load_b(BN2, (c) + 2); }    \
-      if ((c) + 1 < nch) store_a(SN1, ((c) + 1) & 1);                       \
-      compute(BC, (c) & 1);                                                 \
+      if ((c) + 1 < nch) store(SNEXT, ((c) + 1) & 1);                       \
+      if ((c) + 3 < nch) load(SFREE, (c) + 3);                              \
+      compute((c) & 1);                                                     \
       __syncthreads();                                                      \
     }                                                                       \
   } while (0)
-  for (int c = 0; c < nch; c += 6) {
-    FL_LIN_STEP(c + 0, b0, b2, sa1, sa0);
-    FL_LIN_STEP(c + 1, b1, b0, sa0, sa1);
-    FL_LIN_STEP(c + 2, b2, b1, sa1, sa0);
-    FL_LIN_STEP(c + 3, b0, b2, sa0, sa1);
-    FL_LIN_STEP(c + 4, b1, b0, sa1, sa0);
-    FL_LIN_STEP(c + 5, b2, b1, sa0, sa1);
+  // SNEXT holds chunk c+1; SFREE held chunk c (parked one step earlier) and takes chunk c+3
+  for (int c = 0; c < nch; c += 3) {
+    FL_LIN_STEP(c + 0, s1, s0);
+    FL_LIN_STEP(c + 1, s2, s1);
+    FL_LIN_STEP(c + 2, s0, s2);
   }
 #undef FL_LIN_STEP
 
