@@ -537,6 +537,8 @@ def main():
         dt = float(tt)
     final_loss = float(loss)
     assert final_loss == final_loss, "loss is NaN"
+    if tr.persistent:
+        tr.check_programs()   # a timed-out device-wide barrier would have voided the timed steps: raise instead of reporting
     log("timed region: %d steps in %.3f s (loss %.4f); host enqueue %.3f ms/step" % (a.steps, dt, final_loss, 1e3 * t_enq / a.steps))
 
     out = {

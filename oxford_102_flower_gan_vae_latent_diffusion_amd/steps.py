@@ -261,10 +261,25 @@ class DDPMTrainer:
             self.update()
         self.graph = True
 
+    def check_programs(self):
+        """Synchronising health check of the persistent programs (a barrier that timed out voids the run: raises)."""
+        for prog in self._tprog.values():
+            for q in prog.programs:
+                q.check()
+        if self._oprog is not None:
+            self._oprog.prog.check()
+
+    def _replayed(self):
+        # graph replays skip Program.run's own (eager-only) health check: look every 256 steps (one sync)
+        self._replays = getattr(self, "_replays", 0) + 1
+        if self.persistent and self._replays % 256 == 0:
+            self.check_programs()
+
     def replay(self):
         self.g1.replay()
         self.allreduce()
         self.g2.replay()
+        self._replayed()
         return self.loss
 
     # ---- data-parallel step with the gradient all-reduce hidden behind the NEXT batch's encoder ---------------
@@ -313,6 +328,7 @@ class DDPMTrainer:
         if work is not None:
             work.wait()      # the compute stream waits for the collective; the host does not block
         self.gO.replay()
+        self._replayed()
         return self.loss
 
     # ---- cross-step software pipeline -------------------------------------------------------------------
