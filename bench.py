@@ -485,7 +485,8 @@ def main():
     # the denoiser as persistent phase programs (default) needs the whole device: encoder graph -> programs on one stream.
     # FL_TRAIN_PROGRAM=0 restores the multi-kernel denoiser, which runs as a second stream next to the encoder of the next batch
     overlap = use_graph and not a.no_overlap and not tr.persistent
-    dp_overlap = use_graph and tr.persistent and world > 1 and not a.no_overlap   # all-reduce under the next batch's encoder
+    # all-reduce under the next batch's encoder (FL_FORCE_DP_OVERLAP=1: rehearse that schedule on one rank)
+    dp_overlap = use_graph and tr.persistent and not a.no_overlap and (world > 1 or os.environ.get("FL_FORCE_DP_OVERLAP") == "1")
     if dp_overlap:
         tr.capture_overlapped(sdata, slabels)
         tr.prime_overlapped(batches[0], labels[0])
