@@ -465,7 +465,9 @@ def main():
     un = M.ConditionalUNet().to(dev).train()  # the reference trains the denoiser in train() mode (dropout active)
     un.rng.manual_seed(44 + rank)
     ae.rng.manual_seed(42 + rank)
-    tr = steps.DDPMTrainer(ae, un, lr=1e-3, process_group=pg, world_size=world)
+    # ranks sharing ONE device (FL_SHARE_DEVICE rehearsal) cannot each run programs that need every CU: multi-kernel denoiser there
+    share = bool(os.environ.get("FL_SHARE_DEVICE")) and world > 1
+    tr = steps.DDPMTrainer(ae, un, lr=1e-3, process_group=pg, world_size=world, persistent=False if share else None)
     tr.diffusion.rng.manual_seed(1234 + rank)
 
     B = a.batch
