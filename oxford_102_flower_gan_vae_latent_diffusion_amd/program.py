@@ -68,6 +68,11 @@ class ProgramBuilder:
         if self._phases[-1]:
             self._phases.append([])
 
+    def tiles_in_phase(self):
+        """tiles of the jobs added to the current phase so far (as the library counts them)"""
+        L = lib.load()
+        return sum(max(0, L.fl_program_job_tiles(ctypes.c_char_p(j.tobytes()))) for j, _, _ in self._phases[-1])
+
     @staticmethod
     def _key(x):
         """Identity of the buffer behind a pointer argument (for the stale-cache analysis in finalize)."""
