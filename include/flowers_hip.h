@@ -396,7 +396,8 @@ int fl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float
  *   FL_PJOB_ROWNORM  y1 = act(mask * LN(x; W[0], bias[0], eps)) + R + sigmoid(*gate) * aux[1];  C = y1;
  *                    if W[1]: aux[0] = LN(y1; W[1], bias[1], eps2).   N = row width, N % 256 == 0, N <= 1024.
  *   FL_PJOB_SINUSOID C[M,N] = [sin(t*f) | cos(t*f)], t = (int64*)A[0] with element stride lda[0], f = W[0] (N/2 freqs).
- *   FL_PJOB_GATHER   C[M,N] = table A[0] rows picked by (int64*)W[0].
+ *   FL_PJOB_GATHER   C[M,N] = table A[0] rows picked by (int64*)W[0]. K[0] > 0 = the table has K[0] rows: an index outside
+ *                    [0, K[0]) is never dereferenced and voids the run (abort word = 2; Program.check raises).
  *   FL_PJOB_PSAMPLE  the DDPM reverse update (v2:585-592) on C = A[0] = x_t (in place allowed), A[1] = eps_theta:
  *                    x <- (x - (1-a_t)/sqrt(1-ab_t)*eps)/sqrt(a_t) + [t>0] sqrt(beta_t)*z, t = *(int64*)aux[2], tables
  *                    W[0..2] = alpha, alpha_bar, beta; z = A[2] if given, else Philox4x32-10 N(0,1) with seed
@@ -477,7 +478,7 @@ int fl_program_phase_bytes(void);
 int fl_program_job_tiles(const void* job);
 /* Bytes of the barrier area `sync` (arrival counters spread over memory channels, departures, abort flag). */
 int fl_program_sync_bytes(void);
-#define FL_PROG_SYNC_ABORT_WORD (8 * 1024 + 16) /* uint32 index inside `sync`: != 0 after a run = a barrier timed out */
+#define FL_PROG_SYNC_ABORT_WORD (8 * 1024 + 16) /* uint32 index inside `sync`: != 0 after a run = the run is void (1: a barrier timed out, 2: a checked gather index was out of range) */
 /* Run a device-resident program (n_phases*16 + n_jobs*256 bytes <= 29.5 KiB: it is copied to LDS). `io`: HOST array of
  * n_io device pointers (read at call time). `sync`: fl_program_sync_bytes() zeroed device bytes owned by the caller,
  * reused across runs (abort word != 0 afterwards: the run is void and the caller must zero `sync`). max_blocks: 0 =

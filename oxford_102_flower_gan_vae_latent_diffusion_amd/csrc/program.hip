@@ -56,6 +56,7 @@ __shared__ int g_trace_phases, g_trace_p;
 struct ProgIO {
   const void* p[FL_PROG_MAX_IO];
   fl_program_post post;
+  unsigned* abort;  // the abort word inside `sync` (1 = a barrier timed out, 2 = a checked gather index was out of range)
 };
 
 // io slots are bound when the program is copied to LDS (program_kernel): descriptors hold plain addresses here
@@ -589,7 +590,12 @@ __device__ __forceinline__ void gather_tile(const fl_pjob& jb, int r0, int r1, i
   if (i >= r1 * jb.N) return;
   const int b = i / jb.N, d = i - b * jb.N;
   const long long* idx = reinterpret_cast<const long long*>(rp(jb.W[0], io));
-  const float4 v = ld4g(rp(jb.A[0], io) + ldi64g(idx + b) * jb.lda[0] + d);
+  long long ix = ldi64g(idx + b);
+  if (jb.K[0] > 0 && (ix < 0 || ix >= jb.K[0])) {  // checked table (K[0] rows): never read outside it, void the run loudly
+    __hip_atomic_store(io.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ix = 0;
+  }
+  const float4 v = ld4g(rp(jb.A[0], io) + ix * jb.lda[0] + d);
   st4g<WT>(wp(jb.C, io) + (long long)b * jb.ldc + d, v);
 }
 
@@ -1044,11 +1050,13 @@ __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, bo
       if (tot >= target) break;
       __builtin_amdgcn_s_sleep(1);
       ++spins;
-      if ((spins & 255u) == 0 && (spins > SPIN_LIMIT || __hip_atomic_load(&sync[NCTR * CTR_STRIDE + 16], __ATOMIC_RELAXED,
-                                                                         __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        __hip_atomic_store(&sync[NCTR * CTR_STRIDE + 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
+      if ((spins & 255u) == 0) {
+        const unsigned word = __hip_atomic_load(&sync[NCTR * CTR_STRIDE + 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (word != 0 || spins > SPIN_LIMIT) {  // the run is void: keep the first reason (1 = timeout, 2 = gather index)
+          if (word == 0) __hip_atomic_store(&sync[NCTR * CTR_STRIDE + 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
       }
     }
     // The invalidating acquire is only needed when the next phase re-reads a buffer that was overwritten after an
@@ -1082,11 +1090,13 @@ __device__ __forceinline__ bool xcd_barrier(unsigned* sync, int xcc, int slot, u
       if (tot >= target) break;
       __builtin_amdgcn_s_sleep(1);
       ++spins;
-      if ((spins & 255u) == 0 && (spins > SPIN_LIMIT || __hip_atomic_load(&sync[NCTR * CTR_STRIDE + 16], __ATOMIC_RELAXED,
-                                                                         __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        __hip_atomic_store(&sync[NCTR * CTR_STRIDE + 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
+      if ((spins & 255u) == 0) {
+        const unsigned word = __hip_atomic_load(&sync[NCTR * CTR_STRIDE + 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (word != 0 || spins > SPIN_LIMIT) {  // the run is void: keep the first reason (1 = timeout, 2 = gather index)
+          if (word == 0) __hip_atomic_store(&sync[NCTR * CTR_STRIDE + 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
       }
     }
     if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1426,6 +1436,7 @@ int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_job
   for (int i = 0; i < FL_PROG_MAX_IO; ++i) pio.p[i] = i < n_io ? io[i] : nullptr;
   memset(&pio.post, 0, sizeof(pio.post));
   if (post) pio.post = *reinterpret_cast<const fl_program_post*>(post);
+  pio.abort = reinterpret_cast<unsigned*>(sync) + NCTR * CTR_STRIDE + 16;
   for (int i = 0; i < n_io; ++i)
     FL_REQUIRE((reinterpret_cast<uintptr_t>(io[i]) & 15) == 0, "fl_program_run: io[%d] is not 16-byte aligned", i);
   const int cus = device_cus();

@@ -480,12 +480,13 @@ class ConditionalUNet(nn.Module):
         B = x.shape[0]
         shared_t = t.numel() == 1 and B != 1
         if FOLDED_FORWARD and not self.training and c is not None and not shared_t and block_masks is None:
-            # frozen-weight inference: linear chains folded, 13 phases instead of 26 (rebuilt when any weight changes)
+            # frozen-weight inference: linear chains folded, 12 phases instead of 26 (rebuilt when any weight changes); the
+            # per-timestep table covers t < self.max_timesteps (default 1000, v2:564): a larger t voids the run loudly
             cache = self.__dict__.setdefault("_folded", {})
             fp = cache.get((B, x.device))
             if fp is None or fp.key != FoldedUNetProgram.version_key(self):
                 cache.clear()
-                fp = cache[(B, x.device)] = FoldedUNetProgram(self, B, x.device)
+                fp = cache[(B, x.device)] = FoldedUNetProgram(self, B, x.device, n_steps=getattr(self, "max_timesteps", 1000))
             self._pcalls = getattr(self, "_pcalls", 0) + 1
             if self._pcalls % 256 == 0 and not torch.cuda.is_current_stream_capturing():
                 fp.prog.check()

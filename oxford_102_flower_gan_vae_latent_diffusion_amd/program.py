@@ -218,9 +218,11 @@ class ProgramBuilder:
         self._hold(t, freqs, C)
         self._add(j, [t], [C])
 
-    def gather(self, M, N, table, ld_table, idx, C, ldc):
+    def gather(self, M, N, table, ld_table, idx, C, ldc, rows=0):
+        """rows > 0: the table's row count - an index outside [0, rows) voids the run instead of reading outside the table"""
         j = np.zeros((), JOB_DTYPE)
         j["kind"], j["M"], j["N"] = GATHER, M, N
+        j["K"][0] = rows
         j["A"][0], j["lda"][0], j["W"][0], j["C"], j["ldc"] = _ptr(table), ld_table, _ptr(idx), _ptr(C), ldc
         self._hold(table, idx, C)
         self._add(j, [idx], [C])
@@ -317,10 +319,13 @@ class Program:
 
     def check(self):
         """Synchronising health check: raises if a barrier timed out (and re-arms the counters)."""
-        if int(self.sync[SYNC_ABORT_WORD]) != 0:
+        word = int(self.sync[SYNC_ABORT_WORD])
+        if word != 0:
             self.sync.zero_()
             if self._abort_host is not None:
                 self._abort_host.zero_()
+            if word == 2:
+                raise RuntimeError("persistent program aborted: a gather index (timestep / class label) lies outside its table")
             raise RuntimeError("persistent program aborted: a device-wide barrier timed out (is another persistent "
                                "program running on this device?)")
 
@@ -353,7 +358,7 @@ class UNetProgram:
             emb = torch.empty(B, E, **f32)
             ce1a = torch.empty(B, ce_m.lin1.weight.shape[0], **f32)
             ce = torch.empty(B, E, **f32)
-            pb.gather(B, E, d(ce_m.embedding.weight), E, IO(CLS), emb, E)
+            pb.gather(B, E, d(ce_m.embedding.weight), E, IO(CLS), emb, E, rows=ce_m.embedding.weight.shape[0])
         pb.barrier()
         pb.gemm(Bt, H1, [(feat, E, E, d(te_m.lin1.weight), E)], te1a, H1, [(d(te_m.lin1.bias), 1.0)], act=SW)
         if has_class and not ce_given:
@@ -447,22 +452,26 @@ class UNetProgram:
 
 class FoldedUNetProgram:
     """Eval-mode ConditionalUNet forward (per-sample t, class-conditional, no dropout) with the linear chains between the
-    nonlinearities folded, 13 phases instead of 26 (a phase costs ~4.4 us of barrier + hand-over whatever it computes, §3b):
+    nonlinearities folded, 12 phases instead of 26 (a phase costs ~4.4 us of barrier + hand-over whatever it computes, §3b):
       * attention with one token is out_proj(v_proj(.)) and nothing nonlinear follows before the next layer, so
         down(out_proj(v_proj(hn)) + h2) = (W_d W_o W_v) hn + W_d h2 + const is one contraction over [hn | h2]  (as in
         SamplerProgram);
       * the Linear that follows h1 = h + time_proj(tc) is linear in the same inputs, so g = W_lin h1 + b is computed NEXT TO
         h1 in the same phase with pre-multiplied weights (W_lin W_cat, W_lin W_tp) instead of one phase later;
       * layer 0 and the final projections take te1a / ce1a through pre-multiplied weights (W_tp0 W_te2, ...), so nothing on
-        the chain waits for te / ce / tc.
+        the chain waits for te / ce / tc;
+      * te1a = swish(lin1(sinusoid(t))) and ce1a = swish(lin1(embedding(c))) depend on the timestep / the class alone:
+        tables over all n_steps timesteps and all classes, ONE checked gather phase (an index outside its table voids the
+        run loudly) instead of sinusoid + embedding + two GEMM phases.
     The folded weights are products of the module's weights computed once per weight version (`version_key`): this program
     is for frozen weights (inference). Matches v2:534-561 to fp32 re-association (tests/test_program_gpu.py)."""
 
-    def __init__(self, un, B, device):
+    def __init__(self, un, B, device, n_steps=1000):
+        """n_steps: timesteps the per-timestep table covers (t >= n_steps voids the run: Program.check raises)"""
         d = lambda p: p.detach()
         SW = ops.ACT_SWISH
         f32 = dict(dtype=torch.float32, device=device)
-        self.un, self.B, self.key = un, B, self.version_key(un)
+        self.un, self.B, self.key, self.n_steps = un, B, self.version_key(un), n_steps
         E, L = un.time_emb_dim, un.latent_dim
         te_m, ce_m = un.time_emb, un.class_emb
         H1, C1 = te_m.lin1.weight.shape[0], ce_m.lin1.weight.shape[0]
@@ -475,12 +484,16 @@ class FoldedUNetProgram:
         with torch.no_grad():
             Wte2, bte2, Wce2, bce2 = d(te_m.lin2.weight), d(te_m.lin2.bias), d(ce_m.lin2.weight), d(ce_m.lin2.bias)
             bsum = (bte2 + bce2).contiguous()
-            feat, emb, te1a, ce1a, tc = new(B, E), new(B, E), new(B, H1), new(B, C1), new(B, E)
-            pb.sinusoid(B, E, IO(T), 1, un._freqs(device), feat, E)
-            pb.gather(B, E, d(ce_m.embedding.weight), E, IO(CLS), emb, E)
-            pb.barrier()
-            pb.gemm(B, H1, [(feat, E, E, d(te_m.lin1.weight), E)], te1a, H1, [(d(te_m.lin1.bias), 1.0)], act=SW)
-            pb.gemm(B, C1, [(emb, E, E, d(ce_m.lin1.weight), E)], ce1a, C1, [(d(ce_m.lin1.bias), 1.0)], act=SW)
+            te1a, ce1a, tc = new(B, H1), new(B, C1), new(B, E)
+            # x-independent and (frozen weights) a function of the timestep / the class alone: tables over every timestep
+            # and every class, one gather phase instead of sinusoid + embedding + two GEMM phases
+            steps_all = torch.arange(n_steps, dtype=torch.int64, device=device)
+            te_tab = ops.linear(ops.time_sinusoid(steps_all, un._freqs(device)), d(te_m.lin1.weight), d(te_m.lin1.bias), act=SW)
+            ce_tab = ops.linear(d(ce_m.embedding.weight).contiguous(), d(ce_m.lin1.weight), d(ce_m.lin1.bias), act=SW)
+            n_cls = ce_tab.shape[0]
+            keep += [te_tab, ce_tab]
+            pb.gather(B, H1, te_tab, H1, IO(T), te1a, H1, rows=n_steps)
+            pb.gather(B, C1, ce_tab, C1, IO(CLS), ce1a, C1, rows=n_cls)
             pb.barrier()
             pb.gemm(B, E, [(te1a, H1, H1, Wte2, H1), (ce1a, C1, C1, Wce2, C1)], tc, E, [(bte2, 1.0), (bce2, 1.0)])
             # final_time_proj(te) + final_class_proj(ce) (+ the folded constants of the last layer, added below)
@@ -539,7 +552,7 @@ class FoldedUNetProgram:
             pb.rownorm(B, Dl, hpre, Dl, d(fn.weight), d(fn.bias), fn.eps, u, Dl, gate=rw, gx=IO(X), ldgx=L)
             pb.barrier()
             pb.gemm(B, L, [(u, Dl, Dl, d(fin.weight), Dl)], IO(OUT), L, [(d(fin.bias), 1.0)], gate=rw)
-            keep += [Wft2, Wfc2, c_f, extra, hpre, u, bsum, feat, emb, te1a, ce1a, tc]
+            keep += [Wft2, Wfc2, c_f, extra, hpre, u, bsum, te1a, ce1a, tc]
             self.prog = pb.finalize(device)
         self._dummy = torch.zeros(4, **f32)
 

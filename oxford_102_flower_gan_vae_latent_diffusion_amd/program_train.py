@@ -106,7 +106,7 @@ class DenoiserTrainProgram:
         fin = un.final
         rw = d(un.residual_weight)
         pb.sinusoid(B, E, IO(T), 1, un._freqs(device), feat, E)
-        pb.gather(B, E, d(ce_m.embedding.weight), E, IO(CLS), emb, E)
+        pb.gather(B, E, d(ce_m.embedding.weight), E, IO(CLS), emb, E, rows=n_cls)   # a label outside the table voids the run
         pb.gemm(B, L, [(IO(XT), L, L, d(fin.weight), L)], rfin, L, [(d(fin.bias), 1.0)])        # final(x) of v2:561
         pb.barrier()
         pb.gemm(B, H1, [(feat, E, E, d(te_m.lin1.weight), E)], te1a, H1, [(d(te_m.lin1.bias), 1.0)], act=SW, pre_out=te1)

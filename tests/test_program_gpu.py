@@ -169,7 +169,7 @@ def test_unet_program_vs_oracle(dev):
 
 @pytest.mark.parametrize("B", [256, 37])
 def test_folded_unet_program(dev, B):
-    """Eval forward with the linear chains folded (13 phases): vs the multi-kernel engine, vs the oracle, and rebuilt when a
+    """Eval forward with the linear chains folded (12 phases): vs the multi-kernel engine, vs the oracle, and rebuilt when a
     weight changes (torch in-place update or a raw-pointer update announced by FlatParams.bump)."""
     import json
     import os
@@ -184,7 +184,7 @@ def test_folded_unet_program(dev, B):
     xd, td, cd = x.to(dev), t.to(dev), c.to(dev)
     with torch.no_grad():
         fp = P.FoldedUNetProgram(un, B, dev)
-        assert fp.prog.n_phases == 13
+        assert fp.prog.n_phases == 12
         out = fp(xd, td, cd)
         ref_e, _ = engine.unet_forward(un, xd, td, cd)
     fp.prog.check()
@@ -207,6 +207,17 @@ def test_folded_unet_program(dev, B):
         ref4, _ = engine.unet_forward(un, xd, td, cd)
     close(o4, ref4, 3e-5, "after a raw-pointer update")
     assert (o4 - o3).abs().max().item() > 1e-3
+    # a timestep outside the per-timestep table is never dereferenced and voids the run loudly
+    fp2 = P.FoldedUNetProgram(un, B, dev, n_steps=500)
+    with torch.no_grad():
+        fp2(xd, td.clamp(max=499), cd)
+        fp2.prog.check()
+        fp2(xd, torch.full_like(td, 700), cd)
+    with pytest.raises(RuntimeError, match="outside its table"):
+        fp2.prog.check()
+    with torch.no_grad():
+        close(fp2(xd, td.clamp(max=499), cd), engine.unet_forward(un, xd, td.clamp(max=499), cd)[0], 3e-5, "after the abort was cleared")
+    fp2.prog.check()
 
 
 def test_unet_program_ce_given(dev):
