@@ -251,7 +251,10 @@ int fl_attention_fwd(const float* qkv, float* out, float* P, int B, int HW, int 
  * ------------------------------------------------------------------------ */
 int fl_res_tail_map(const float* y, const float* scale, const float* shift, const float* s, int s_per_image, float* map,
                     int B, int HW, int C, fl_stream_t stream);
-/* fl_res_tail_out_pre: as fl_res_tail_out, with the residual given before its LayerNorm2d-apply + Swish:
+/* With map AND att_out the spatial-attention gate sigmoid(conv7x7(map)) is computed by its own one-thread-per-pixel kernel into
+ * att_out first and the channel pass only streams (the 98-tap stencil inside the streaming pass cost 59 of 135 us at 32x32x128);
+ * without att_out the gate is computed inside the pass.
+ * fl_res_tail_out_pre: as fl_res_tail_out, with the residual given before its LayerNorm2d-apply + Swish:
  * xres := swish(xres * xres_scale[b,c] + xres_shift[b,c]) (the block input is never materialised, engine.encoder_infer). */
 int fl_res_tail_out_pre(const float* y, const float* scale, const float* shift, const float* s, int s_per_image, const float* map,
                         const float* saw, const float* xres, const float* xres_scale, const float* xres_shift, float* out,

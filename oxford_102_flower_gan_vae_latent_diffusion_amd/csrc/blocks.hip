@@ -79,7 +79,8 @@ __global__ void res_tail_out_kernel(const float* __restrict__ y, const float* __
                                     const float* __restrict__ map, const float* __restrict__ saw,
                                     const float* __restrict__ xres, const float* __restrict__ xs,
                                     const float* __restrict__ xh, float* __restrict__ out, float* __restrict__ att_out,
-                                    int B, int H, int W, int C, int final_swish, int s_per_image) {
+                                    int B, int H, int W, int C, int final_swish, int s_per_image,
+                                    const float* __restrict__ att_in) {
   constexpr int PPW = 64 / LPP;
   __shared__ float wsm[98];
   if (map) {
@@ -100,7 +101,9 @@ __global__ void res_tail_out_kernel(const float* __restrict__ y, const float* __
     const int b = (int)(pp / HW);
     const int p = (int)(pp - (long long)b * HW);
     float att = 1.f;
-    if (map) {
+    if (att_in) {  // the spatial-attention gate was computed by sa_att_kernel: this pass only streams
+      att = att_in[pp];
+    } else if (map) {
       const int py = p / W, px = p - py * W;
       float a = 0.f;
       for (int t = gl; t < 98; t += LPP) {
@@ -137,6 +140,41 @@ __global__ void res_tail_out_kernel(const float* __restrict__ y, const float* __
       }
       st4(out + off, u);
     }
+  }
+}
+
+// att[b, p] = sigmoid(conv7x7([mean | max] map, saw)) (v2:76-79): one thread per pixel on the L2-resident 2-plane map.
+// Inside res_tail_out_kernel the 98-tap stencil (lanes splitting the taps, a shuffle tree, the sigmoid) sat in front of every
+// pixel's channel stream and cost 59 of its 135 us at the 32x32x128 stage (tools/res_tail_probe.py).
+__global__ __launch_bounds__(256) void sa_att_kernel(const float* __restrict__ map, const float* __restrict__ saw,
+                                                     float* __restrict__ att, int B, int H, int W) {
+  // one image per block: its two map planes with a zero halo of 3 in LDS, then 98 unconditional LDS reads per pixel
+  extern __shared__ float sm[];  // [98 weights][2][(H + 6)][(W + 6)]
+  float* wsm = sm;
+  float* pm = sm + 98;
+  const int HW = H * W, Wp = W + 6, plane = (H + 6) * Wp;
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < 98; i += blockDim.x) wsm[i] = saw[i];
+  for (int i = threadIdx.x; i < 2 * plane; i += blockDim.x) {
+    const int ch = i / plane, r = i - ch * plane;
+    const int yy = r / Wp - 3, xx = r - (r / Wp) * Wp - 3;
+    pm[i] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? map[((long long)b * 2 + ch) * HW + yy * W + xx] : 0.f;
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const int py = p / W, px = p - py * W;
+    // 98 taps summed in fp64 (exact products, one rounding at the end): the gate's own gradient (v2:76-79 backward) is
+    // ill-conditioned enough that the summation order of an fp32 stencil shows in it (tests/test_golden_r2_gpu.py)
+    double a = 0.0;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const float* m = pm + ch * plane + py * Wp + px;  // window origin (py - 3, px - 3) in padded coordinates
+#pragma unroll
+      for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 7; ++dx) a += (double)wsm[ch * 49 + dy * 7 + dx] * (double)m[dy * Wp + dx];
+    }
+    att[(long long)b * HW + p] = fl::sigmoid_acc((float)a);
   }
 }
 
@@ -184,7 +222,14 @@ int fl_res_tail_out_pre(const float* y, const float* scale, const float* shift, 
   const long long npix = (long long)B * H * W;
   if (npix == 0) return FL_OK;
   const int C4 = C / 4;
-#define LAUNCH_OUT(L) hipLaunchKernelGGL(res_tail_out_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, saw, xres, xres_scale, xres_shift, out, att_out, B, H, W, C, final_swish, s_per_image)
+  const float* att_in = nullptr;
+  if (map && att_out && (98 + 2 * (H + 6) * (W + 6)) * (int)sizeof(float) <= 48 * 1024) {  // gate first (its own small kernel, into the buffer the caller keeps anyway), then the streaming pass
+    hipLaunchKernelGGL(sa_att_kernel, dim3(B), dim3(256), (98 + 2 * (H + 6) * (W + 6)) * sizeof(float), st, map, saw, att_out, B, H, W);
+    att_in = att_out;
+    att_out = nullptr;
+    map = nullptr;
+  }
+#define LAUNCH_OUT(L) hipLaunchKernelGGL(res_tail_out_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, saw, xres, xres_scale, xres_shift, out, att_out, B, H, W, C, final_swish, s_per_image, att_in)
   if (C4 >= 64) LAUNCH_OUT(64);
   else if (C4 >= 32) LAUNCH_OUT(32);
   else if (C4 >= 16) LAUNCH_OUT(16);

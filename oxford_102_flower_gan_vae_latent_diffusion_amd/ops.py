@@ -525,7 +525,8 @@ def res_tail_out(y, scale=None, shift=None, s=None, map_=None, saw=None, xres=No
     _chk(y, scale, shift, s, map_, saw, xres)
     B, H, W, C = y.shape
     out = torch.empty_like(y)
-    att = new((B, H, W), y) if save_att else None
+    # with a map the library computes the gate in its own small kernel INTO this buffer first, then streams (fl_res_tail_out_pre)
+    att = new((B, H, W), y) if (save_att or map_ is not None) else None
     spi = int(s is not None and s.dim() == 2)
     xs, xh = xres_pre if xres_pre is not None else (None, None)
     _chk(xs, xh)
