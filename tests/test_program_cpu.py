@@ -136,3 +136,46 @@ def test_training_shape_rules_are_enforced(bad):
         pb.adam(1002, z(1002), z(1002), z(1002), z(1002), z(256), z(1), z(1, dtype=torch.int32), 0.9, 0.999, 1e-8, 0.0, True)
     with pytest.raises(ValueError):
         pb.finalize("cpu")
+
+
+def test_weight_gradient_deferral_places_pieces_only_on_idle_blocks():
+    """program_train._Deferral (host logic): jobs are cut into pieces of <= 128 tiles, a piece goes into a phase only if
+    that many blocks are idle there, strips are emitted in order and everything left lands in the last phase."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd.program_train import _Deferral
+
+    class StubBuilder:
+        def __init__(self):
+            self.phase_tiles, self.closed = 0, []
+
+        def tiles_in_phase(self):
+            return self.phase_tiles
+
+        def barrier(self):
+            self.closed.append(self.phase_tiles)
+            self.phase_tiles = 0
+
+    pb = StubBuilder()
+    dq = _Deferral(pb, blocks=256, piece_tiles=128)
+    emitted = []
+
+    def mk(name, per):
+        def emit(s0, ns):
+            emitted.append((name, s0, ns))
+            pb.phase_tiles += ns * per
+        return emit
+
+    dq.add(mk("a", 16), 16, 16)     # 1024 x 1024: 16 strips of 16 tiles -> two pieces of 8 strips
+    dq.add(mk("b", 8), 16, 8)       # 1024 x 512: 16 strips of 8 tiles -> one piece
+    pb.phase_tiles = 256            # a full phase: nothing fits
+    dq.end_phase()
+    assert emitted == [] and pb.closed == [256]
+    pb.phase_tiles = 64             # 192 idle blocks: exactly one piece
+    dq.end_phase()
+    assert emitted == [("a", 0, 8)] and pb.closed[-1] == 192
+    pb.phase_tiles = 0              # an empty phase takes two pieces (256 blocks)
+    dq.end_phase()
+    assert emitted[1:] == [("a", 8, 8), ("b", 0, 16)] and pb.closed[-1] == 256
+    dq.add(mk("c", 16), 16, 16)
+    pb.phase_tiles = 200
+    dq.end_phase(last=True)         # the last phase takes whatever is left, in order
+    assert emitted[3:] == [("c", 0, 8), ("c", 8, 8)] and not dq.q
