@@ -90,3 +90,26 @@ for p in range(nph - 1):
     tot += d.mean()
     print("%-3d %7.2f %7.2f   tiles %6.2f  (%d tiles)" % (p, d.mean(), d.max(), tile, int(jobs_per_phase[p, 2])))
 print("sum of mean phase durations %.1f us; launch span %.1f us" % (tot, tr[:, nph - 1, 2].max() - tr[:, 0, 0].min()))
+
+# where a phase's time beyond its slowest tile goes (over the blocks that ran a tile):
+#   drain  = tiles done -> barrier entered (s_waitcnt vmcnt(0) on the write-through stores + __syncthreads)
+#   detect = the LAST block's arrive -> the FIRST block leaving (one poll round trip after the last arrival)
+#   skew   = first block leaving -> last block leaving;  start = last block leaving -> the next phase's first tile start
+print("\nbarrier anatomy per phase (us): slowest tile | drain (mean / of the slowest block) | detect | skew | next start")
+acc = [0.0] * 5
+for p in range(nph - 1):
+    ran = (tr[:, p, 2] - tr[:, p, 0]) > 0.3
+    if not ran.any():
+        continue
+    tile_end = tr[:, p, 2]
+    slow = int(torch.argmax(torch.where(ran, tile_end, torch.full_like(tile_end, -1e30))))
+    drain_mean = (tr[ran, p, 3] - tr[ran, p, 2]).mean()
+    drain_slow = tr[slow, p, 3] - tr[slow, p, 2]
+    last_arrive = tr[:, p, 5].max()
+    first_leave, last_leave = tr[:, p, 6].min(), tr[:, p, 6].max()
+    nxt = tr[:, p + 1, 0].min()
+    vals = [tile_end[slow] - tr[slow, p, 0], drain_slow, first_leave - last_arrive, last_leave - first_leave, nxt - last_leave]
+    for i, v in enumerate(vals):
+        acc[i] += float(v)
+    print("%-3d %6.2f | %5.2f / %5.2f | %5.2f | %5.2f | %5.2f" % (p, vals[0], drain_mean, drain_slow, vals[2], vals[3], vals[4]))
+print("sums: slowest tiles %.1f, drain %.1f, detect %.1f, skew %.1f, next start %.1f us" % tuple(acc))
