@@ -432,7 +432,7 @@ class ConditionalUNet(nn.Module):
             self._freq_cache[device] = f
         return f
 
-    def dropout_masks(self, B, device):
+    def dropout_masks(self, B, device, defer=False):
         """Philox dropout-scale tensors for train mode: (block_masks, head_masks). With one dropout rate everywhere (the
         reference's dropout_rate feeds both nn.Dropout and the attention dropout, v2:503-516) all eight masks are slices of
         ONE draw: 2 launches instead of 16 in the step's dependent kernel chain; elements stay independent (counter-based)."""
@@ -441,20 +441,22 @@ class ConditionalUNet(nn.Module):
         rates = {block[2].p for block, _, _ in self.layers} | {self.attention_layers[i].dropout for i in range(len(self.layers))}
         if len(rates) == 1:
             sizes = [B * d for d in dims] + [B * h for h in heads]
-            flat = self.rng.dropout((sum(sizes),), device, rates.pop())
+            # defer=True: the caller bumps this stream's counter itself (by the returned count) - see rng.Philox
+            flat = self.rng.dropout((sum(sizes),), device, rates.pop(), advance=not defer)
             parts, o = [], 0
             for n in sizes:
                 parts.append(flat[o:o + n])
                 o += n
             L = len(dims)
-            return ([parts[i].view(B, dims[i]) for i in range(L)], [parts[L + i].view(B, heads[i]) for i in range(L)])
+            out = ([parts[i].view(B, dims[i]) for i in range(L)], [parts[L + i].view(B, heads[i]) for i in range(L)])
+            return out + (self.rng.fill_count(sum(sizes)),) if defer else out
         bm, hm = [], []
         for i, (block, _, _) in enumerate(self.layers):
             d = block[0].weight.shape[0]
             bm.append(self.rng.dropout((B, d), device, block[2].p))
             att = self.attention_layers[i]
             hm.append(self.rng.dropout((B, att.num_heads), device, att.dropout))
-        return bm, hm
+        return (bm, hm, 0) if defer else (bm, hm)   # several draws: advanced as usual, nothing left to defer
 
     def forward(self, x, t, c=None, block_masks=None, head_masks=None):
         x = _f32c(x)

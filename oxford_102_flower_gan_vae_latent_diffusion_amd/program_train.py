@@ -241,7 +241,8 @@ class DenoiserTrainProgram:
     def programs(self):
         return (self.prog,)
 
-    def run(self, xt, t, labels, eps, block_masks=None, head_masks=None):
+    def run(self, xt, t, labels, eps, block_masks=None, head_masks=None, post=None):
+        """post: [(int64 device counter, delta), ...] (at most two) bumped once after the last phase (Philox offsets)"""
         B = self.B
         assert xt.shape[0] == B and t.numel() == B and labels.numel() == B and eps.shape == xt.shape
         ops._chk(xt, t, labels, eps)
@@ -251,7 +252,7 @@ class DenoiserTrainProgram:
             for i in range(len(self.un.layers)):
                 ops._chk(block_masks[i], head_masks[i])
                 io[BM0 + i], io[HM0 + i] = block_masks[i], head_masks[i]
-        self.prog.run(io)
+        self.prog.run(io, post=post or None)
         return self.out
 
 

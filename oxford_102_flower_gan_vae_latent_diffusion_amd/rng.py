@@ -29,26 +29,35 @@ class Philox:
             self._state[key] = s
         return s
 
-    def _fill(self, out, mode, p=0.0):
+    # offset / advance: a caller that draws several tensors in a row and has a kernel of its own to bump the counter
+    # afterwards (the persistent training program's post hook) passes the counters consumed so far as `offset` and
+    # advance=False, then adds `fill_count(numel)` / `numel` (randint) itself - same numbers, fewer tiny launches.
+    @staticmethod
+    def fill_count(numel):
+        return (numel + 3) // 4
+
+    def _fill(self, out, mode, p=0.0, offset=0, advance=True):
         st = self.state(out.device)
-        ops.philox_fill(out, self.seed, 0, st, mode, p)
-        ops.advance_offset(st, (out.numel() + 3) // 4)
+        ops.philox_fill(out, self.seed, offset, st, mode, p)
+        if advance:
+            ops.advance_offset(st, offset + (out.numel() + 3) // 4)
         return out
 
-    def normal(self, shape, device, out=None):
+    def normal(self, shape, device, out=None, offset=0, advance=True):
         out = out if out is not None else torch.empty(tuple(shape), dtype=torch.float32, device=device)
-        return self._fill(out, 0)
+        return self._fill(out, 0, 0.0, offset, advance)
 
     def uniform(self, shape, device):
         return self._fill(torch.empty(tuple(shape), dtype=torch.float32, device=device), 2)
 
-    def dropout(self, shape, device, p):
+    def dropout(self, shape, device, p, offset=0, advance=True):
         """scale tensor: 0 with probability p, else 1/(1-p)."""
-        return self._fill(torch.empty(tuple(shape), dtype=torch.float32, device=device), 1, p)
+        return self._fill(torch.empty(tuple(shape), dtype=torch.float32, device=device), 1, p, offset, advance)
 
-    def randint(self, shape, device, hi):
+    def randint(self, shape, device, hi, offset=0, advance=True):
         out = torch.empty(tuple(shape), dtype=torch.int64, device=device)
         st = self.state(device)
-        ops.philox_randint(out, self.seed, hi, 0, st)
-        ops.advance_offset(st, out.numel())
+        ops.philox_randint(out, self.seed, hi, offset, st)
+        if advance:
+            ops.advance_offset(st, offset + out.numel())
         return out

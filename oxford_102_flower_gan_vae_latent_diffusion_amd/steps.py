@@ -185,16 +185,26 @@ class DDPMTrainer:
     def fwd_bwd(self, z, labels, t=None, eps=None, block_masks=None, head_masks=None):
         d = self.diffusion
         B = z.shape[0]
+        use_prog = self.persistent and labels is not None and (t is None or t.numel() == B) and self._program_shapes_ok()
+        # on the program path the Philox counters of this step's draws are bumped by the program's post hook (the last block
+        # to leave) instead of one tiny launch per draw: same numbers (offset = counters consumed so far)
+        d_adv = m_adv = 0
         if t is None:
-            t = d.rng.randint((B,), z.device, d.n_steps)
+            t = d.rng.randint((B,), z.device, d.n_steps, advance=not use_prog)
+            d_adv += B
         if eps is None:
-            eps = d.rng.normal(z.shape, z.device)
+            eps = d.rng.normal(z.shape, z.device, offset=d_adv if use_prog else 0, advance=not use_prog)
+            d_adv += d.rng.fill_count(z.numel())
         if self.unet.training and block_masks is None and self.unet.dropout_rate > 0:
-            block_masks, head_masks = self.unet.dropout_masks(B, z.device)
+            if use_prog:
+                block_masks, head_masks, m_adv = self.unet.dropout_masks(B, z.device, defer=True)
+            else:
+                block_masks, head_masks = self.unet.dropout_masks(B, z.device)
         xt = ops.q_sample(z, eps, t, d.alpha_bar)
-        if self.persistent and labels is not None and t.numel() == B and self._program_shapes_ok():
+        if use_prog:
             prog = self._train_program(B, block_masks is not None)
-            self.eps_theta = prog.run(xt, t, labels, eps, block_masks, head_masks)   # loss and every gradient included
+            post = [(r.state(z.device), n) for r, n in ((d.rng, d_adv), (self.unet.rng, m_adv)) if n]
+            self.eps_theta = prog.run(xt, t, labels, eps, block_masks, head_masks, post=post)   # loss and every gradient included
             return
         eps_theta, S = engine.unet_forward(self.unet, xt, t, labels, block_masks, head_masks, save=True)
         loss, norms = ops.euclid_loss_fwd(eps_theta, eps)
