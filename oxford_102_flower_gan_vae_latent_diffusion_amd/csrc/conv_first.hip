@@ -15,8 +15,15 @@ namespace {
 constexpr int GPW = 8;  // 32-pixel groups per wave
 
 // ACT: activation fixed at compile time (a runtime switch inside the unrolled groups spills)
-template <bool STATS, int ACT>
-__global__ __launch_bounds__(256, 3) void conv3x3_c4_o64_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+
+// H2: f16x2 split math (the scheme of conv_h2.hip) instead of the fp32 MFMA - the 36 MFMAs of 64 cycles per 32 pixels were
+// 39 us of this 97 us kernel and did not overlap its 268 MB of stores; 18 MFMAs of 32 cycles are not worth mentioning. The
+// weights are scaled by the power of two that puts their largest magnitude in [2^14, 2^15) (found by the wave itself) and
+// split once per wave; the taps are scaled by 2^6 (|x| < 1023: images, VGG-normalised images; larger inputs give NaN, loudly)
+// and split per pixel group. k = 4 tap + channel: group g of 16 k = taps 4g..4g+3 (lane half lh: taps 4g+2lh, 4g+2lh+1).
+template <bool STATS, int ACT, bool H2>
+__global__ __launch_bounds__(256, H2 ? 2 : 3) void conv3x3_c4_o64_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              float* __restrict__ partial, int H, int W, float act_param) {
   const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
@@ -30,10 +37,38 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c4_o64_kernel(const float* __r
 
   // B fragments: step s (k = 2s + lh), channel tile j (co = 32j + lr);  wp = [64][3][3][4] -> w[k][co] = wp[co*36 + k]
   float wf[18][2];
+  if constexpr (!H2) {
 #pragma unroll
-  for (int s = 0; s < 18; ++s) {
-    wf[s][0] = wp[lr * 36 + 2 * s + lh];
-    wf[s][1] = wp[(32 + lr) * 36 + 2 * s + lh];
+    for (int s = 0; s < 18; ++s) {
+      wf[s][0] = wp[lr * 36 + 2 * s + lh];
+      wf[s][1] = wp[(32 + lr) * 36 + 2 * s + lh];
+    }
+  }
+  h8_t wh[3][2], wl[3][2];
+  float out_scale = 1.f;
+  constexpr float XS = 64.f;  // 2^6
+  if constexpr (H2) {
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) m = fmaxf(m, fmaxf(fabsf(wp[lr * 36 + k]), fabsf(wp[(32 + lr) * 36 + k])));
+    m = fl::wave_max(m);
+    const int E = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    int e = E ? 141 - E : 0;  // m * 2^e in [2^14, 2^15)
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    const float sw = __uint_as_float((unsigned)(e + 127) << 23);
+    out_scale = __uint_as_float((unsigned)(127 - e) << 23) * (1.0f / XS);
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = 16 * g + 8 * lh + q;
+          const float X = k < 36 ? wp[(32 * j + lr) * 36 + k] * sw : 0.f;
+          const _Float16 hh = (_Float16)X;
+          wh[g][j][q] = hh;
+          wl[g][j][q] = (_Float16)(X - (float)hh);
+        }
   }
   const float b0 = bias ? bias[lr] : 0.f, b1 = bias ? bias[32 + lr] : 0.f;
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -71,14 +106,39 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c4_o64_kernel(const float* __r
     f32x16 a0, a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.f;
+    if constexpr (H2) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float lo = lh ? tp[g & 1][t][1] : tp[g & 1][t][0];  // k = 4t + lh      (channels 0/1)
-      const float hi = lh ? tp[g & 1][t][3] : tp[g & 1][t][2];  // k = 4t + 2 + lh  (channels 2/3)
-      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lo, wf[2 * t][0], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(lo, wf[2 * t][1], a1, 0, 0, 0);
-      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(hi, wf[2 * t + 1][0], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(hi, wf[2 * t + 1][1], a1, 0, 0, 0);
+      for (int kg = 0; kg < 3; ++kg) {
+        // this lane's 8 k values of group kg: taps 4 kg + 2 lh and 4 kg + 2 lh + 1 (tap 9.. = padding: zeros)
+        const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4v ta = lh ? (4 * kg + 2 < 9 ? tp[g & 1][4 * kg + 2 < 9 ? 4 * kg + 2 : 0] : z) : tp[g & 1][4 * kg < 9 ? 4 * kg : 0];
+        const f32x4v tb = lh ? (4 * kg + 3 < 9 ? tp[g & 1][4 * kg + 3 < 9 ? 4 * kg + 3 : 0] : z)
+                             : (4 * kg + 1 < 9 ? tp[g & 1][4 * kg + 1 < 9 ? 4 * kg + 1 : 0] : z);
+        h8_t ah, al;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float X = (q < 4 ? ta[q & 3] : tb[q & 3]) * XS;
+          const _Float16 hh = (_Float16)X;
+          ah[q] = hh;
+          al[q] = (_Float16)(X - (float)hh);
+        }
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[kg][0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[kg][1], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[kg][0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[kg][1], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[kg][0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[kg][1], a1, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float lo = lh ? tp[g & 1][t][1] : tp[g & 1][t][0];  // k = 4t + lh      (channels 0/1)
+        const float hi = lh ? tp[g & 1][t][3] : tp[g & 1][t][2];  // k = 4t + 2 + lh  (channels 2/3)
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lo, wf[2 * t][0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(lo, wf[2 * t][1], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(hi, wf[2 * t + 1][0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(hi, wf[2 * t + 1][1], a1, 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     // C/D layout: channel = lane&31 (+32 for a1), pixel = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -86,7 +146,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c4_o64_kernel(const float* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned cst = (unsigned)(((r & 3) + 8 * (r >> 2)) * 64);
-      float v0 = a0[r] + b0, v1 = a1[r] + b1;
+      float v0 = (H2 ? a0[r] * out_scale : a0[r]) + b0, v1 = (H2 ? a1[r] * out_scale : a1[r]) + b1;
       if (STATS) {
         s1[0] += v0; s2[0] += v0 * v0;
         s1[1] += v1; s2[1] += v1 * v1;
@@ -129,10 +189,13 @@ int conv3x3_c4_o64_slabs(int H, int W) { return (H * W) / (32 * GPW); }
 
 // partial (nullable): [B][S][2][64] sums / sums of squares of the biased, pre-activation output, S = H*W/(32*GPW)
 int launch_conv3x3_c4_o64(const float* x, const float* wp, const float* bias, float* y, float* partial, int B, int H, int W,
-                          int act, float act_param, hipStream_t s) {
+                          int act, float act_param, hipStream_t s, int math) {
   const int blocks = (int)(((long long)B * H * W) / (4 * 32 * GPW));
-#define FL_STEM(ST, AC) \
-  hipLaunchKernelGGL((conv3x3_c4_o64_kernel<ST, AC>), dim3(blocks), dim3(256), 0, s, x, wp, bias, y, partial, H, W, act_param)
+#define FL_STEM(ST, AC)                                                                                                          \
+  do {                                                                                                                           \
+    if (math) hipLaunchKernelGGL((conv3x3_c4_o64_kernel<ST, AC, true>), dim3(blocks), dim3(256), 0, s, x, wp, bias, y, partial, H, W, act_param); \
+    else hipLaunchKernelGGL((conv3x3_c4_o64_kernel<ST, AC, false>), dim3(blocks), dim3(256), 0, s, x, wp, bias, y, partial, H, W, act_param);    \
+  } while (0)
   if (partial) {
     if (act != FL_ACT_NONE) {
       set_error("conv3x3_c4_o64: fused statistics are taken before the activation; act must be NONE");

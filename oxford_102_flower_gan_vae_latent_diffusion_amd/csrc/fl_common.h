@@ -86,8 +86,9 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // fl_conv2d_fwd / fl_conv2d_fwd_instnorm entry points of gemm.hip when the shape matches
 bool conv3x3_c4_o64_applicable(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int act);
 int conv3x3_c4_o64_slabs(int H, int W);
+// math: 0 = fp32 MFMA, 1 = f16x2 split math (inputs |x| < 1023)
 int launch_conv3x3_c4_o64(const float* x, const float* wp, const float* bias, float* y, float* partial, int B, int H, int W,
-                          int act, float act_param, hipStream_t s);
+                          int act, float act_param, hipStream_t s, int math);
 
 // 3x3 / stride 1 / pad 1 conv with pre-split weights, halo staged once per channel chunk (conv_halo.hip)
 bool conv3x3_halo_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);

@@ -1130,7 +1130,7 @@ int fl_conv2d_fwd_instnorm(const float* x, const float* wp, const float* bias, f
   if (fl::conv3x3_c4_o64_applicable(B, H, W, Cin, Cout, kh, kw, stride, pad, FL_ACT_NONE)) {  // RGB stem: dedicated kernel (conv_first.hip)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float* partial = reinterpret_cast<float*>(ws);
-    const int rc0 = fl::launch_conv3x3_c4_o64(x, wp, bias, y, partial, B, H, W, FL_ACT_NONE, 0.f, st);
+    const int rc0 = fl::launch_conv3x3_c4_o64(x, wp, bias, y, partial, B, H, W, FL_ACT_NONE, 0.f, st, gemm_math());
     if (rc0) return rc0;
     hipLaunchKernelGGL(conv_inorm_finalize, dim3(fl::cdiv((long long)B * Cout, 256)), dim3(256), 0, st, partial, ln_w, ln_b, eps,
                        scale, shift, mean, rstd, B, HW, Cout, fl::conv3x3_c4_o64_slabs(H, W));
@@ -1193,7 +1193,7 @@ int fl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, 
   const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
   FL_REQUIRE(Ho > 0 && Wo > 0, "fl_conv2d_fwd: empty output");
   if (!R && !out_nchw && fl::conv3x3_c4_o64_applicable(B, H, W, Cin, Cout, kh, kw, stride, pad, act))  // RGB stem (conv_first.hip)
-    return fl::launch_conv3x3_c4_o64(x, wp, bias, y, nullptr, B, H, W, act, act_param, reinterpret_cast<hipStream_t>(stream));
+    return fl::launch_conv3x3_c4_o64(x, wp, bias, y, nullptr, B, H, W, act, act_param, reinterpret_cast<hipStream_t>(stream), gemm_math());
   GArgs g = base_args();
   g.M = B * Ho * Wo; g.N = Cout; g.K = kh * kw * Cin;
   g.A = x; g.a_vec = is_vec(x, Cin);
