@@ -8,6 +8,8 @@
 // v_mfma_f32_32x32x2_f32 with K = 36 exactly, the accumulators go straight to HBM (each store instruction writes
 // two full 128-byte lines), and the LayerNorm2d statistics of the output (v2:152-153) are summed in registers and
 // written as one slab per wave in the layout conv_inorm_finalize (gemm.hip) already consumes.
+#include <cstdlib>
+
 #include "fl_common.h"
 
 namespace {
@@ -191,6 +193,8 @@ int conv3x3_c4_o64_slabs(int H, int W) { return (H * W) / (32 * GPW); }
 int launch_conv3x3_c4_o64(const float* x, const float* wp, const float* bias, float* y, float* partial, int B, int H, int W,
                           int act, float act_param, hipStream_t s, int math) {
   const int blocks = (int)(((long long)B * H * W) / (4 * 32 * GPW));
+  static const bool force_fp32 = getenv("FL_STEM_FP32") != nullptr;  // timing knob: the fp32-MFMA variant in split mode too
+  if (force_fp32) math = 0;
 #define FL_STEM(ST, AC)                                                                                                          \
   do {                                                                                                                           \
     if (math) hipLaunchKernelGGL((conv3x3_c4_o64_kernel<ST, AC, true>), dim3(blocks), dim3(256), 0, s, x, wp, bias, y, partial, H, W, act_param); \
