@@ -280,6 +280,9 @@ class DDPMTrainer:
             self._oprog.prog.check()
 
     def _replayed(self):
+        # a replayed optimizer graph updates the weights through raw pointers without running FlatParams.bump(): tell the
+        # weight-version consumers (program.FoldedUNetProgram) that the denoiser's weights moved
+        self.unet._raw_epoch = getattr(self.unet, "_raw_epoch", 0) + 1
         # graph replays skip Program.run's own (eager-only) health check: look every 256 steps (one sync)
         self._replays = getattr(self, "_replays", 0) + 1
         if self.persistent and self._replays % 256 == 0:
@@ -419,6 +422,7 @@ class DDPMTrainer:
             self.gU.replay()
             self.allreduce()
             self.gO.replay()
+        self.unet._raw_epoch = getattr(self.unet, "_raw_epoch", 0) + 1
         return self.loss
 
     def sync_pipeline(self):
@@ -501,6 +505,10 @@ class VAEGANTrainer:
 
     def replay(self):
         self.graph.replay()
+        # the graph's own packs were made from the weights BEFORE its update: eager code that runs after a replay (evaluation,
+        # sampling, a checkpointed decode) must re-derive its packed layouts from the weights the graph left behind
+        self.fp.bump()
+        self.dfp.bump()
         return self.out
 
     @torch.no_grad()

@@ -194,6 +194,12 @@ def test_vae_gan_capture_replay_equals_eager(dev):
         if a.numel() > 4_000_000:
             a, b = a.reshape(-1)[:1 << 20], b.reshape(-1)[:1 << 20]
         close(b.float(), a.float(), 1e-6, "AE " + n)
+    # eager inference after replays sees the weights the last replay wrote (packed layouts re-derived, not the graph's)
+    with torch.no_grad():
+        ae1.eval(), ae2.eval()
+        z0 = torch.zeros(B, ae1.latent_dim, device=dev)
+        ra, rb = ae1(d, eps=z0)[0], ae2(d, eps=z0)[0]
+    close(rb, ra, 2e-5, "eager reconstruction after replays")
 
 
 def test_vae_gan_resume_across_schedule_boundary(dev, tmp_path):
