@@ -444,7 +444,11 @@ int fl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float
 enum { FL_PJOB_GEMM = 0, FL_PJOB_ROWNORM = 1, FL_PJOB_SINUSOID = 2, FL_PJOB_GATHER = 3, FL_PJOB_PSAMPLE = 4,
        FL_PJOB_LNBWD = 5, FL_PJOB_LNCOL = 6, FL_PJOB_LOSS = 7, FL_PJOB_FIN = 8, FL_PJOB_EWADD = 9, FL_PJOB_EMBBWD = 10,
        FL_PJOB_SQNORM = 11, FL_PJOB_ADAM = 12 };
-enum { FL_PG_TA = 1, FL_PG_TW = 2, FL_PG_COLSUM = 4, FL_PG_ACTBWD = 8, FL_PG_DECOUPLED = 16, FL_PG_T64 = 32 };
+enum { FL_PG_TA = 1, FL_PG_TW = 2, FL_PG_COLSUM = 4, FL_PG_ACTBWD = 8, FL_PG_DECOUPLED = 16, FL_PG_T64 = 32,
+       FL_PG_DMA = 64,     /* set by fl_program_job_layout: a GEMM job whose operands go global -> LDS by LDS-DMA (not TA, every
+                              K_s % 128 == 0, operands 16-byte aligned): 4-stage ring of 128-wide k chunks */
+       FL_PG_WCONST = 128  /* set by the builder: no job of the program writes this GEMM job's W operands (weights), so a block
+                              may request their first chunks BEFORE the barrier that precedes the job's phase */ };
 typedef struct fl_pjob {
   uint64_t A[FL_PROG_MAX_SEG], W[FL_PROG_MAX_SEG], bias[FL_PROG_MAX_SEG];
   uint64_t R, C, mask, gate;
@@ -457,7 +461,8 @@ typedef struct fl_pjob {
   float eps, eps2;
   int32_t bias_row_stride, flags;
   float alpha;
-  int32_t ld2, pad_[2];
+  int32_t ld2;
+  int32_t nrt, per; /* filled by fl_program_job_layout: the job's tiles are nrt row tiles x per tiles each */
 } fl_pjob; /* 256 bytes (one 32-bit word per lane of a wave), no implicit padding */
 /* Counters bumped once per run, after the last phase, by the last block to leave (the device-resident DDPM step
  * counter in its int32 and int64 forms, the Philox offset): ptr == 0 entries are skipped. */
@@ -469,6 +474,12 @@ typedef struct fl_program_post {
 } fl_program_post;
 #define FL_PPHASE_ACQUIRE 1 /* flags: invalidate L1/L2 before this phase (it re-reads a buffer that an earlier phase of
                               the same run overwrote AFTER some block had read it; a run starts with clean caches) */
+#define FL_PPHASE_LOCAL 2   /* flags: every job of the phase is row-local (row tile rt of each job only needs row tile rt of
+                              what earlier phases produced): with FL_PROG_XCD_LOCAL the row tiles are dealt to the XCDs
+                              (rt % 8, by HW_REG_XCC_ID), outputs are stored with plain stores (they stay in that XCD's L2)
+                              and two consecutive local phases are separated by a barrier among that XCD's blocks only
+                              (a flag line in L2); a local phase followed by a device-wide phase ends in an L2 write-back
+                              + the device-wide barrier */
 typedef struct fl_pphase {
   int32_t job_begin, job_end, ntiles, flags;
 } fl_pphase;
@@ -479,17 +490,19 @@ int fl_program_phase_bytes(void);
  * GATHER, PSAMPLE, EWADD: ceil(32*N/4/256); LNBWD, LOSS: 8; LNCOL: N/32, EMBBWD: K[0], FIN: 1, SQNORM, ADAM: 256 in all);
  * negative fl_status if the job violates the shape rules above. `job` is a HOST pointer. */
 int fl_program_job_tiles(const void* job);
+/* The same check; also fills job->nrt / job->per and sets or clears FL_PG_DMA in job->flags (`job` is a writable HOST
+ * pointer). Every job handed to fl_program_run must have been through this call. Returns the tile count. */
+int fl_program_job_layout(void* job);
 /* Bytes of the barrier area `sync` (arrival counters spread over memory channels, departures, abort flag). */
 int fl_program_sync_bytes(void);
-#define FL_PROG_SYNC_ABORT_WORD (8 * 1024 + 16) /* uint32 index inside `sync`: != 0 after a run = the run is void (1: a barrier timed out, 2: a checked gather index was out of range) */
+#define FL_PROG_SYNC_ABORT_WORD (8 * 1024 + 16) /* uint32 index inside `sync`: != 0 after a run = the run is void (1: a barrier timed out, 2: a checked gather index was out of range, 3: the grid's blocks were not spread evenly over the XCDs (FL_PROG_XCD_LOCAL)) */
 /* Run a device-resident program (n_phases*16 + n_jobs*256 bytes <= 29.5 KiB: it is copied to LDS). `io`: HOST array of
  * n_io device pointers (read at call time). `sync`: fl_program_sync_bytes() zeroed device bytes owned by the caller,
  * reused across runs (abort word != 0 afterwards: the run is void and the caller must zero `sync`). max_blocks: 0 =
  * one block per CU. Concurrent runs must not share `sync`; two programs running at once on one device may each wait
  * for CUs the other holds until the barrier timeout fires. `post`: HOST pointer to an fl_program_post, or NULL. */
-#define FL_PROG_XCD_LOCAL 1 /* flags: every job of the program works on the same batch rows (same M, no broadcast producer):
-                              32-row tiles are dealt to the XCDs (by HW_REG_XCC_ID census), phases hand data over through
-                              the XCD's own L2 and end in a barrier among that XCD's blocks only */
+#define FL_PROG_XCD_LOCAL 1 /* flags: honour FL_PPHASE_LOCAL (without it every phase is device-wide: write-through stores,
+                              device-wide barriers, any block runs any tile) */
 int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_jobs, const void* const* io, int n_io,
                    void* sync, int max_blocks, int flags, const void* post, fl_stream_t stream);
 

@@ -16,8 +16,10 @@ from . import lib, ops
 import os
 
 GEMM, ROWNORM, SINUSOID, GATHER, PSAMPLE, LNBWD, LNCOL, LOSS, FIN, EWADD, EMBBWD, SQNORM, ADAM = range(13)
-PG_TA, PG_TW, PG_COLSUM, PG_ACTBWD, PG_DECOUPLED, PG_T64 = 1, 2, 4, 8, 16, 32
-LOCAL_DEFAULT = os.environ.get("FL_PROG_LOCAL", "0") == "1"  # opt-in XCD-local execution (same speed, see program.hip)
+PG_TA, PG_TW, PG_COLSUM, PG_ACTBWD, PG_DECOUPLED, PG_T64, PG_DMA, PG_WCONST = 1, 2, 4, 8, 16, 32, 64, 128
+# XCD-local execution of the row-local phases (program.hip): on by default, FL_PROG_LOCAL=0 runs every phase device-wide
+LOCAL_DEFAULT = os.environ.get("FL_PROG_LOCAL", "1") != "0"
+ROW_KINDS = (GEMM, ROWNORM, SINUSOID, GATHER, PSAMPLE, LNBWD, LOSS, EWADD)  # row tile rt of the output needs row tile rt of the inputs
 MAX_IO = 16
 
 JOB_DTYPE = np.dtype([
@@ -25,10 +27,10 @@ JOB_DTYPE = np.dtype([
     ("aux", "<u8", 4), ("kind", "<i4"), ("M", "<i4"), ("N", "<i4"), ("nseg", "<i4"), ("K", "<i4", 3), ("lda", "<i4", 3),
     ("ldw", "<i4", 3), ("ldr", "<i4"), ("ldc", "<i4"), ("act", "<i4"), ("mask_group", "<i4"), ("tile_begin", "<i4"),
     ("ntiles", "<i4"), ("bias_scale", "<f4", 3), ("eps", "<f4"), ("eps2", "<f4"), ("bias_row_stride", "<i4"), ("flags", "<i4"),
-    ("alpha", "<f4"), ("ld2", "<i4"), ("pad_", "<i4", 2)])
+    ("alpha", "<f4"), ("ld2", "<i4"), ("nrt", "<i4"), ("per", "<i4")])
 POST_DTYPE = np.dtype([("ptr64", "<u8", 2), ("delta64", "<i8", 2), ("ptr32", "<u8"), ("delta32", "<i4"), ("pad_", "<i4")])
 PHASE_DTYPE = np.dtype([("job_begin", "<i4"), ("job_end", "<i4"), ("ntiles", "<i4"), ("flags", "<i4")])
-PHASE_ACQUIRE = 1
+PHASE_ACQUIRE, PHASE_LOCAL = 1, 2
 SYNC_ABORT_WORD = 8 * 1024 + 16
 
 
@@ -55,6 +57,7 @@ class ProgramBuilder:
     def __init__(self):
         self._phases = [[]]
         self._keep = []  # tensors whose storage the program points into
+        self._wkeys = {}  # id(job array) -> buffers behind a GEMM job's W operands
 
     def _hold(self, *xs):
         for x in xs:
@@ -84,9 +87,10 @@ class ProgramBuilder:
             x = x[0]
         return ("mem", x.untyped_storage().data_ptr())
 
-    def _add(self, job, reads, writes):
+    def _add(self, job, reads, writes, weights=()):
         self._phases[-1].append((job, [self._key(r) for r in reads if r is not None],
                                  [self._key(w) for w in writes if w is not None]))
+        self._wkeys[id(job)] = [self._key(w) for w in weights if w is not None]
 
     def gemm(self, M, N, segs, C, ldc, biases=(), act=ops.ACT_NONE, R=None, ldr=0, mask=None, mask_group=0, gate=None,
              bias_row_index=None, bias_row_stride=0, ta=False, tw=False, colsum=None, colsum_alpha=1.0, actbwd=None,
@@ -115,7 +119,7 @@ class ProgramBuilder:
         j["aux"][2], j["bias_row_stride"] = _ptr(bias_row_index), bias_row_stride
         self._hold(C, R, mask, gate, bias_row_index)
         self._add(j, [a[0] for a in segs] + [a[3] for a in segs if ta or tw] + [R, mask, bias_row_index, actbwd],
-                  [C, colsum, pre_out])
+                  [C, colsum, pre_out], weights=[a[3] for a in segs])
 
     def lnbwd(self, M, D, x, ldx, dy, lddy, w, b, eps, dx, ld, act=ops.ACT_NONE, mask=None, R=None, ldr=0, gl=None, stats=None):
         """row LayerNorm backward: dx = LN'(dy * act'(u) * mask) + R; gl (optional) receives the gradient w.r.t. the LN
@@ -246,6 +250,13 @@ class ProgramBuilder:
         jobs = []
         ph = np.zeros(len(phases), PHASE_DTYPE)
         max_tiles = 0
+        written = set(k for p in phases for _, _, w in p for k in w)
+        # XCD-local execution of a phase (its row tiles never leave their XCD) is legal when all of its jobs are row-local
+        # and work on the same batch rows as every other row-local job of the program
+        row_ms = set(int(j["M"]) for p in phases for j, _, _ in p
+                     if int(j["kind"]) in ROW_KINDS and not (int(j["kind"]) == GEMM and int(j["flags"]) & PG_TA))
+        local_ok = len(row_ms) == 1
+        m_ref = next(iter(row_ms)) if local_ok else -1
         # A run starts with clean caches and the barrier only writes dirty lines back. A phase needs the invalidating
         # acquire iff it reads a buffer that was overwritten after some block may have cached an older version of it.
         cached, stale = set(), set()
@@ -259,25 +270,32 @@ class ProgramBuilder:
             cached |= reads
             ph[pi]["job_begin"] = len(jobs)
             t0 = 0
+            all_rows = local_ok
             for j, _, _ in p:
-                buf = j.tobytes()
-                n = L.fl_program_job_tiles(ctypes.c_char_p(buf))
+                kind, flags = int(j["kind"]), int(j["flags"])
+                if kind == GEMM and not (set(self._wkeys.get(id(j), ())) & written):
+                    j["flags"] = flags | PG_WCONST   # its W operands are weights: never written by the program
+                buf = ctypes.create_string_buffer(j.tobytes(), JOB_DTYPE.itemsize)
+                n = L.fl_program_job_layout(buf)
                 if n < 0:
                     raise ValueError("program job rejected: %s" % lib.last_error())
+                laid = np.frombuffer(buf.raw, dtype=JOB_DTYPE)[0]
+                j["nrt"], j["per"], j["flags"] = laid["nrt"], laid["per"], laid["flags"]
                 j["tile_begin"], j["ntiles"] = t0, n
                 t0 += n
                 jobs.append(j)
+                all_rows = all_rows and kind in ROW_KINDS and not (kind == GEMM and flags & PG_TA) and int(j["M"]) == m_ref
+            if all_rows:
+                ph[pi]["flags"] |= PHASE_LOCAL
             ph[pi]["job_end"], ph[pi]["ntiles"] = len(jobs), t0
             max_tiles = max(max_tiles, t0)
-        # XCD-local execution (rows never cross XCDs) is legal when every job works on the same batch rows
-        ms = set(int(j["M"]) for j in jobs)
-        local_ok = len(ms) == 1
         jobs_np = np.stack(jobs)
         jobs_t = torch.from_numpy(np.frombuffer(jobs_np.tobytes(), dtype=np.uint8).copy()).to(device)
         ph_t = torch.from_numpy(np.frombuffer(ph.tobytes(), dtype=np.uint8).copy()).to(device)
         prog = Program(ph_t, jobs_t, len(phases), len(jobs), max_tiles, self._keep, device)
         prog.local_ok = local_ok
         prog.local = local_ok and LOCAL_DEFAULT
+        prog.n_local_phases = int(((ph["flags"] & PHASE_LOCAL) != 0).sum())
         return prog
 
 
@@ -288,8 +306,9 @@ class Program:
         self.sync = torch.zeros(lib.load().fl_program_sync_bytes() // 4, dtype=torch.int32, device=device)
         self._abort_host = torch.zeros(1, dtype=torch.int32).pin_memory() if str(device).startswith("cuda") else None
         self.max_blocks = 0  # 0 = one block per CU
-        self.local_ok = False  # every job works on the same batch rows: XCD-local execution is legal
-        self.local = False     # FL_PROG_XCD_LOCAL requested (only honoured by the builder when local_ok)
+        self.local_ok = False  # the row-local jobs all work on the same batch rows: phases flagged PHASE_LOCAL may run XCD-local
+        self.local = False     # ask for FL_PROG_XCD_LOCAL (set by the builder when local_ok; FL_PROG_LOCAL=0 turns it off)
+        self.n_local_phases = 0
 
     def run(self, io, post=None):
         """io: list of tensors bound to the IO slots. Enqueues one kernel on the current stream (graph-capturable).
@@ -326,6 +345,9 @@ class Program:
                 self._abort_host.zero_()
             if word == 2:
                 raise RuntimeError("persistent program aborted: a gather index (timestep / class label) lies outside its table")
+            if word == 3:
+                raise RuntimeError("persistent program aborted: the grid's blocks were not spread evenly over the XCDs "
+                                   "(XCD-local phases need that; FL_PROG_LOCAL=0 runs every phase device-wide)")
             raise RuntimeError("persistent program aborted: a device-wide barrier timed out (is another persistent "
                                "program running on this device?)")
 

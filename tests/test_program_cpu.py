@@ -74,7 +74,9 @@ def test_acquire_only_where_a_cached_buffer_was_overwritten():
     pb.gemm(64, 64, [(a, 64, 64, w, 64)], b, 64)   # re-reads a after the overwrite -> acquire
     pb.barrier()
     pb.gemm(64, 64, [(c, 64, 64, w, 64)], a, 64)   # the acquire dropped every cached line: c is read fresh -> none
-    assert list(phases_of(pb.finalize("cpu"))["flags"]) == [0, 0, 0, 0, P.PHASE_ACQUIRE, 0]
+    flags = phases_of(pb.finalize("cpu"))["flags"]
+    assert list(flags & P.PHASE_ACQUIRE) == [0, 0, 0, 0, P.PHASE_ACQUIRE, 0]
+    assert all(flags & P.PHASE_LOCAL)   # six row-local GEMM phases on the same 64 rows
 
 
 def test_io_slots_are_encoded_as_small_integers():
@@ -110,8 +112,38 @@ def test_training_job_kinds_tile_counts():
     prog = pb.finalize("cpu")
     jb = jobs_of(prog)
     assert list(jb["ntiles"]) == [32, 64, 16, 24, 16, 24, 1, 24, 102, 256, 256]
-    assert list(jb["flags"][:3]) == [P.PG_TW, P.PG_TA | P.PG_TW | P.PG_COLSUM, P.PG_TA | P.PG_TW | P.PG_T64]
+    derived = P.PG_DMA | P.PG_WCONST   # set by fl_program_job_layout / the builder's weight analysis
+    assert list(jb["flags"][:3] & ~derived) == [P.PG_TW, P.PG_TA | P.PG_TW | P.PG_COLSUM, P.PG_TA | P.PG_TW | P.PG_T64]
+    assert jb["flags"][0] & P.PG_DMA and not jb["flags"][1] & P.PG_DMA and not jb["flags"][2] & P.PG_DMA   # never a TA operand
     assert jb["flags"][-1] == P.PG_DECOUPLED and prog.n_phases == 4
+    assert list(jb["nrt"] * jb["per"]) == list(jb["ntiles"])
+    # rows 70 vs 256: the row-local jobs do not share their rows -> no local phase
+    assert not prog.local_ok and not any(phases_of(prog)["flags"] & P.PHASE_LOCAL)
+
+
+def test_local_phases_dma_and_constant_weights():
+    """Which phases may run XCD-local, which GEMMs take the LDS-DMA tile, which may have their weights prefetched."""
+    z = torch.zeros
+    B = 64
+    pb = P.ProgramBuilder()
+    x, w1, h, w2, y = z(B, 256), z(128, 256), z(B, 128), z(256, 128), z(B, 256)
+    dy, dx, gw = z(B, 256), z(B, 128), z(256, 128)
+    pb.gemm(B, 128, [(x, 256, 256, w1, 256)], h, 128)                         # row-local, K % 128 == 0: DMA, constant weights
+    pb.barrier()
+    pb.gemm(B, 256, [(h, 128, 128, w2, 128)], y, 256)
+    pb.rownorm(B, 256, x, 256, z(256), z(256), 1e-5, z(B, 256), 256)
+    pb.barrier()
+    pb.gemm(B, 128, [(dy, 256, 256, w2, 128)], dx, 128, tw=True)              # dgrad: row-local, DMA
+    pb.gemm(256, 128, [(dy, 256, B, h, 128)], gw, 128, ta=True, tw=True)      # wgrad: contraction over the batch -> device-wide phase
+    pb.barrier()
+    pb.gemm(B, 96, [(x, 256, 200, z(96, 200), 200)], z(B, 96), 96)            # K % 128 != 0: register-staged tile
+    pb.gemm(B, 128, [(x, 256, 256, h, 256)], z(B, 128), 128)                  # "weights" that the program itself writes (h)
+    prog = pb.finalize("cpu")
+    ph, jb = phases_of(prog), jobs_of(prog)
+    assert prog.local_ok and prog.local == P.LOCAL_DEFAULT and prog.n_local_phases == 3
+    assert [bool(f & P.PHASE_LOCAL) for f in ph["flags"]] == [True, True, False, True]
+    assert [bool(f & P.PG_DMA) for f in jb["flags"]] == [True, True, False, True, False, False, True]
+    assert [bool(f & P.PG_WCONST) for f in jb["flags"][[0, 1, 3, 5, 6]]] == [True, True, True, True, False]
 
 
 @pytest.mark.parametrize("bad", ["ta_alone", "ta_ragged", "t64_epilogue", "t64_shape", "lnbwd_D", "lnbwd_two_stage", "adam_n"])

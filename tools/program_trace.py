@@ -26,6 +26,8 @@ if TRAIN:  # the two-launch training step's forward+backward program (program_tr
     up = DenoiserTrainProgram(un, fp.gviews, B, dev)
     eps_t = torch.randn(B, 256, device=dev)
     bm, hm = un.dropout_masks(B, dev)
+elif os.environ.get("FOLDED", "0") == "1":  # the eval-mode forward with folded chains (what ConditionalUNet.forward runs)
+    up = P.FoldedUNetProgram(un, B, dev)
 else:
     up = P.UNetProgram(un, B, dev)
 nph = up.prog.n_phases
@@ -49,21 +51,28 @@ def run():
 for _ in range(5):
     run()
 torch.cuda.synchronize()
+trace.zero_()   # stamps a tile kind does not write stay 0 = "missing" below
+run()
+torch.cuda.synchronize()
+up.prog.check()
 tr = trace.view(G, nph, 12).cpu().double() * 0.01  # us
+print("program: %d phases, %d of them XCD-local (FL_PROG_LOCAL=%s)" % (nph, up.prog.n_local_phases, os.environ.get("FL_PROG_LOCAL", "1")))
 t0 = tr[:, 0, 0].min()
 print("blocks %d phases %d; total %.1f us (first phase start -> last phase tiles done)" % (G, nph, tr[:, nph - 1, 2].max() - t0))
 print("%-5s %8s %8s | %8s %8s %8s %8s %8s | %s" % ("phase", "start", "len", "tiles", "mfma", "fence", "atomic", "spin", "busy blocks"))
 jobs_per_phase = up.prog.phases.cpu().view(torch.int32).view(-1, 4)
 for p in range(nph):
     s = tr[:, p, 0]
-    busy = (tr[:, p, 1] > 0) if True else None
     tiles_done = tr[:, p, 2]
     ntiles = int(jobs_per_phase[p, 2])
-    act = slice(0, min(ntiles, G))
+    act = (tr[:, p, 2] - tr[:, p, 0]) > 0.3   # blocks that ran a tile (local phases deal tiles by XCD slot, not by block id)
+    if not act.any():
+        act = tr[:, p, 0] > 0
     start = s.min() - t0
     end = (tr[:, p, 6].max() if p + 1 < nph else tiles_done.max()) - t0
     tile_t = (tiles_done[act] - s[act]).mean()
-    mf = (tr[act, p, 1] - s[act]).clamp(min=0).mean() if (tr[act, p, 1] > 0).any() else float("nan")
+    m1 = act & (tr[:, p, 1] > 0)
+    mf = (tr[m1, p, 1] - s[m1]).mean() if m1.any() else float("nan")
     if p + 1 < nph:
         fence = (tr[:, p, 4] - tr[:, p, 3]).mean()
         atom = (tr[:, p, 5] - tr[:, p, 4]).mean()
@@ -72,10 +81,16 @@ for p in range(nph):
     else:
         fence = atom = spin = float("nan")
     det = ""
-    if (tr[act, p, 7] > 0).any():
-        a = act
-        det = " ptrs %.2f issue %.2f loop %.2f epi %.2f" % ((tr[a, p, 7] - s[a]).mean(), (tr[a, p, 8] - tr[a, p, 7]).mean(),
-                                                          (tr[a, p, 1] - tr[a, p, 8]).mean(), (tr[a, p, 2] - tr[a, p, 1]).mean())
+    a = (tr[:, p, 7] > 0) & (tr[:, p, 8] > 0) & (tr[:, p, 1] > 0)   # blocks whose LAST tile of the phase was a stamped GEMM tile
+    if a.any():
+        det = " ptrs %.2f issue %.2f loop %.2f epi %.2f (%d blocks; last tile of each)" % (
+            (tr[a, p, 7] - s[a]).mean(), (tr[a, p, 8] - tr[a, p, 7]).mean(), (tr[a, p, 1] - tr[a, p, 8]).mean(),
+            (tr[a, p, 2] - tr[a, p, 1]).mean(), int(a.sum()))
+        b = a & (tr[:, p, 9] > 0) & (tr[:, p, 10] > 0)    # LDS-DMA tiles: first chunk landed, partial tiles merged
+        if b.any():
+            det += " [first chunk %.2f, chunks %.2f, merge %.2f, epilogue+prefetch %.2f]" % (
+                (tr[b, p, 9] - tr[b, p, 8]).mean(), (tr[b, p, 1] - tr[b, p, 9]).mean(), (tr[b, p, 10] - tr[b, p, 1]).mean(),
+                (tr[b, p, 2] - tr[b, p, 10]).mean())
     cyc = trace.view(G, nph, 12)[act, p, 11].double().cpu()
     mhz = (cyc / (tiles_done[act] - s[act])).mean()
     print("%-5d %8.2f %8.2f | %8.2f %8.2f %8.2f %8.2f %8.2f | %d tiles%s  clk %.0f MHz" % (p, start, end - start, tile_t, mf, fence, atom, spin, ntiles, det, mhz))
