@@ -447,8 +447,12 @@ enum { FL_PJOB_GEMM = 0, FL_PJOB_ROWNORM = 1, FL_PJOB_SINUSOID = 2, FL_PJOB_GATH
 enum { FL_PG_TA = 1, FL_PG_TW = 2, FL_PG_COLSUM = 4, FL_PG_ACTBWD = 8, FL_PG_DECOUPLED = 16, FL_PG_T64 = 32,
        FL_PG_DMA = 64,     /* set by fl_program_job_layout: a GEMM job whose operands go global -> LDS by LDS-DMA (not TA, every
                               K_s % 128 == 0, operands 16-byte aligned): 4-stage ring of 128-wide k chunks */
-       FL_PG_WCONST = 128  /* set by the builder: no job of the program writes this GEMM job's W operands (weights), so a block
-                              may request their first chunks BEFORE the barrier that precedes the job's phase */ };
+       FL_PG_WCONST = 128, /* set by the builder: no job of the program writes this GEMM job's W operands (weights), so a block
+                              may request their first chunks BEFORE the barrier that precedes the job's phase */
+       FL_PG_WPACK = 256   /* (with FL_PG_DMA, not TW) every W_s points to fl_program_pack_weight's image of the [N][K_s] weight
+                              (ldw_s unused): the 16 KB a (32-column tile, 128-k chunk) needs are one contiguous run in LDS image
+                              order. Frozen weights only (inference programs): the row-major walk costs 1.5x the time per chunk
+                              (tools/dma_rate_probe.hip, variants 4 / 7) */ };
 typedef struct fl_pjob {
   uint64_t A[FL_PROG_MAX_SEG], W[FL_PROG_MAX_SEG], bias[FL_PROG_MAX_SEG];
   uint64_t R, C, mask, gate;
@@ -480,19 +484,25 @@ typedef struct fl_program_post {
                               and two consecutive local phases are separated by a barrier among that XCD's blocks only
                               (a flag line in L2); a local phase followed by a device-wide phase ends in an L2 write-back
                               + the device-wide barrier */
+#define FL_PPHASE_RINGSAFE 4 /* flags: no job of the phase touches the GEMM tiles' LDS rings (only ROWNORM, SINUSOID, GATHER, PSAMPLE,
+                              LNBWD, LOSS, EWADD jobs): a block may stream the weights of its first GEMM tile of the phase AFTER
+                              this one into LDS while it runs this phase's tiles */
 typedef struct fl_pphase {
   int32_t job_begin, job_end, ntiles, flags;
 } fl_pphase;
 /* sizeof(fl_pjob) / sizeof(fl_pphase) as compiled: the host-side builder asserts its packing against these */
 int fl_program_job_bytes(void);
 int fl_program_phase_bytes(void);
-/* tiles a job occupies = ceil(M/32) row tiles x tiles per row tile (GEMM: N/32 (FL_PG_T64: M/64 x N/64 in all); ROWNORM: 8; SINUSOID: ceil(32*N/2/256);
+/* tiles a job occupies = ceil(M/32) row tiles x tiles per row tile (GEMM: N/32 (FL_PG_T64: M/64 x N/64 in all); ROWNORM: 32 (one row per tile, a quarter row per wave); SINUSOID: ceil(32*N/2/256);
  * GATHER, PSAMPLE, EWADD: ceil(32*N/4/256); LNBWD, LOSS: 8; LNCOL: N/32, EMBBWD: K[0], FIN: 1, SQNORM, ADAM: 256 in all);
  * negative fl_status if the job violates the shape rules above. `job` is a HOST pointer. */
 int fl_program_job_tiles(const void* job);
 /* The same check; also fills job->nrt / job->per and sets or clears FL_PG_DMA in job->flags (`job` is a writable HOST
  * pointer). Every job handed to fl_program_run must have been through this call. Returns the tile count. */
 int fl_program_job_layout(void* job);
+/* out[((ct * (K/128) + c) * 32 + r) * 128 + 4 * pb + e] = w[(32 ct + r) * ldw + 128 c + 4 * (pb ^ (r & 15)) + e]: the weight [N][K]
+ * (row pitch ldw floats; N % 32 == 0, K % 128 == 0) as FL_PG_WPACK reads it; out = N * K floats. */
+int fl_program_pack_weight(const float* w, float* out, int N, int K, int ldw, fl_stream_t stream);
 /* Bytes of the barrier area `sync` (arrival counters spread over memory channels, departures, abort flag). */
 int fl_program_sync_bytes(void);
 #define FL_PROG_SYNC_ABORT_WORD (8 * 1024 + 16) /* uint32 index inside `sync`: != 0 after a run = the run is void (1: a barrier timed out, 2: a checked gather index was out of range, 3: the grid's blocks were not spread evenly over the XCDs (FL_PROG_XCD_LOCAL)) */

@@ -33,29 +33,33 @@ constexpr int STAGE = 2 * TS * LDK;  // floats per LDS stage: 32 A rows then 32 
 constexpr int SLD = 36;            // LDS row stride of a partial output tile (floats)
 constexpr int PROG_LDS_BYTES = 30 * 1024 - 512;  // LDS copy of the program (phases + jobs); 512 bytes left for the statics
 constexpr int LDS_BYTES = 2 * STAGE * 4 + PROG_LDS_BYTES;
-// LDS-DMA GEMM tile (FL_PG_DMA): 4-stage ring of 128-wide k chunks, 16 KB per operand and stage, unpadded images whose
+// LDS-DMA GEMM tile (FL_PG_DMA): rings of 128-wide k chunks (3 A slots, 5 W slots of 16 KB), unpadded images whose
 // 16-byte column blocks are XOR-swizzled by the row (the swizzle is applied on the GLOBAL side of the DMA: lane L lands at
 // LDS byte 16 L whatever it fetched)
 constexpr int DKC = 128;                 // k values per chunk (32 per wave)
-constexpr int DIMG = TS * DKC;           // floats per operand image
-constexpr int DSTAGE = 2 * DIMG;         // floats per ring stage (A image, then W image)
-constexpr int DSTAGES = 4;
-static_assert(DSTAGES * DSTAGE <= 2 * STAGE, "the DMA ring lives in the two register-staged stages' LDS");
+constexpr int DIMG = TS * DKC;           // floats per operand image (16 KB)
+constexpr int NA = 3, NW = 5;            // ring slots: A chunk c in slot c % 3, W chunk c in slot 3 + c % 5
+static_assert((NA + NW) * DIMG <= 2 * STAGE, "the DMA rings live in the two register-staged stages' LDS");
 constexpr int NCTR = 8;            // arrival counters
 constexpr int CTR_STRIDE = 1024;   // ... this many uints apart (4 KB)
 constexpr int SYNC_UINTS = (NCTR + 1) * CTR_STRIDE;
 constexpr unsigned SPIN_LIMIT = 1u << 21;  // barrier polls before a run is declared dead (~ seconds)
 
-// -DFL_PROG_TRACE: timing-only build; io slot 15 is a uint64 buffer [block][phase][12] of 100 MHz wall-clock stamps
+// -DFL_PROG_TRACE: timing-only build; io slot 15 is a uint64 buffer [block][phase][16] of 100 MHz wall-clock stamps
 #ifndef FL_PROG_TRACE
 #define FL_PROG_TRACE 0
+#endif
+// -DFL_PG_ABLATE=n: timing-only builds of the LDS-DMA GEMM tile (WRONG results): 1 no MFMAs, 2 no W loads behind the prologue,
+// 3 no A loads behind the prologue, 4 no fragment reads, 5 = 2 + 3
+#ifndef FL_PG_ABLATE
+#define FL_PG_ABLATE 0
 #endif
 #if FL_PROG_TRACE
 __shared__ unsigned long long* g_trace;  // only thread 0 of the block touches these
 __shared__ int g_trace_phases, g_trace_p;
 #define FL_STAMP(k)                                                                                        \
   do {                                                                                                     \
-    if (threadIdx.x == 0 && g_trace) g_trace[((size_t)blockIdx.x * g_trace_phases + g_trace_p) * 12 + (k)] = wall_clock64(); \
+    if (threadIdx.x == 0 && g_trace) g_trace[((size_t)blockIdx.x * g_trace_phases + g_trace_p) * 16 + (k)] = wall_clock64(); \
   } while (0)
 #else
 #define FL_STAMP(k) do {} while (0)
@@ -118,10 +122,15 @@ __device__ __forceinline__ uint64_t ldsp(jobwords_t p, int word) {
   return (uint64_t)(unsigned)ldsi(p, word) | ((uint64_t)(unsigned)ldsi(p, word + 1) << 32);
 }
 #define FL_JW(f) ((int)(offsetof(fl_pjob, f) / 4))
-__device__ __forceinline__ void load_job(const int* src /* LDS */, fl_pjob& d) {
+// The block keeps a decoded tile's descriptor as ONE VGPR (`jobwords_t`: lane i = word i, fetch_job) and every tile kind
+// unpacks just the fields it uses, where it runs (load_job): two whole descriptors in scalar registers (the running tile's and
+// the next one's) cost ~600 SGPR spills and a microsecond per tile.
+__device__ __forceinline__ jobwords_t fetch_job(const int* src /* LDS */) {
   static_assert(sizeof(fl_pjob) / 4 <= 64, "descriptor must fit one word per lane");
   const int ln = threadIdx.x & 63;
-  const jobwords_t p = ((lint_p)src)[ln < (int)(sizeof(fl_pjob) / 4) ? ln : 0];
+  return ((lint_p)src)[ln < (int)(sizeof(fl_pjob) / 4) ? ln : 0];
+}
+__device__ __forceinline__ void load_job(const jobwords_t p, fl_pjob& d) {
 #pragma unroll
   for (int s = 0; s < FL_PROG_MAX_SEG; ++s) {
     d.A[s] = ldsp(p, FL_JW(A) + 2 * s);
@@ -177,10 +186,11 @@ __device__ __forceinline__ float act_grad(float u, int act) {
 // per ds_read_b32: both conflict-free) instead of [32][256 + 4].
 template <bool TA, bool TW>
 __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, const ProgIO& io, float* smem, const bool wt) {
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+  const int tidx = threadIdx.x & 255;  // waves 4-7 of the 512-thread block shadow waves 0-3 (same loads, same LDS words, same stores)
+  const int w = __builtin_amdgcn_readfirstlane(tidx >> 6);
+  const int lane = tidx & 63, lr = lane & 31, lh = lane >> 5;
   const int kq4 = lane * 4;  // this thread's k offset inside a chunk row (a wave covers one whole 256-wide row slice)
-  const int tr = threadIdx.x >> 3, tc4 = (threadIdx.x & 7) * 4;  // transposed operands: chunk rows tr + 32 i, 4 columns
+  const int tr = tidx >> 3, tc4 = (tidx & 7) * 4;  // transposed operands: chunk rows tr + 32 i, 4 columns
 
   // chunk bookkeeping (all scalar): segment s owns chunks [cb_s, cb_{s+1})
   const float* A0 = rp(jb.A[0], io);
@@ -290,7 +300,7 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
   do {                                                                                             \
     if constexpr (TA) {                                                                            \
       if (colsum) {                                                                                \
-        const float* Ia_ = smem + (st) * STAGE + (threadIdx.x >> 5) * 32 * TS + (threadIdx.x & 31); \
+        const float* Ia_ = smem + (st) * STAGE + (tidx >> 5) * 32 * TS + (tidx & 31); \
         _Pragma("unroll 8") for (int j_ = 0; j_ < 32; ++j_) cs += *(const lf1_t*)(Ia_ + j_ * TS);  \
       }                                                                                            \
     }                                                                                              \
@@ -301,7 +311,7 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   // epilogue operands are requested first: they ride along with the chunk loads instead of costing a memory round
   // trip (about 1 us here) after the contraction
-  const int er = threadIdx.x >> 3, ec = (threadIdx.x & 7) * 4;
+  const int er = tidx >> 3, ec = (tidx & 7) * 4;
   const int gr = rt * TS + er, gc = ct * TS + ec;
   const int grc = gr < jb.M ? gr : jb.M - 1;
   float4 e_b[FL_PROG_MAX_SEG], e_r = make_float4(0.f, 0.f, 0.f, 0.f), e_p = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -321,29 +331,21 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
   if (jb.mask) e_m = ld1g(rp(jb.mask, io) + (long long)grc * (jb.N / jb.mask_group) + gc / jb.mask_group);
   if (jb.R) e_r = ld4g(rp(jb.R, io) + (long long)grc * jb.ldr + gc);
   if (actbwd) e_p = ld4g(rp(jb.aux[1], io) + (long long)grc * jb.ld2 + gc);
-  Stage R0, R1;
-  bool ok0 = false, ok1 = false;
-  int kv0 = 0, kv1 = 0;
+  // ONE register stage, two LDS stages (this tile only serves operands the LDS-DMA tile does not take: TA weight-gradient
+  // tiles that are not 64 x 64, K not a multiple of 128): chunk c + 1 is in flight while chunk c is contracted. Parking
+  // chunk c into stage c & 1 is safe once the wave has passed iteration c - 1's barrier (every wave has then left chunk c - 2).
+  Stage R0;
+  bool ok0 = false;
+  int kv0 = 0;
   FL_STAMP(7);
-  // (chunks past the last one are not requested: a one-chunk tile - every weight-gradient tile at batch 256 - would
-  // otherwise fetch its operands four times over)
   FL_ISSUE(R0, 0, ok0, kv0);
-  if (nC > 1) FL_ISSUE(R1, 1, ok1, kv1);
   FL_STAMP(8);
-  for (int c = 0; c < nC; c += 2) {
-    FL_PARK(R0, ok0, kv0, 0);
-    if (c + 2 < nC) FL_ISSUE(R0, c + 2, ok0, kv0);
+  for (int c = 0; c < nC; ++c) {
+    FL_PARK(R0, ok0, kv0, c & 1);
+    if (c + 1 < nC) FL_ISSUE(R0, c + 1, ok0, kv0);
     __syncthreads();
-    FL_CONTRACT(0);
-    FL_COLSUM(0);
-    const bool more = c + 1 < nC;  // block-uniform
-    if (more) FL_PARK(R1, ok1, kv1, 1);
-    if (c + 3 < nC) FL_ISSUE(R1, c + 3, ok1, kv1);
-    __syncthreads();
-    if (more) {
-      FL_CONTRACT(1);
-      FL_COLSUM(1);
-    }
+    FL_CONTRACT(c & 1);
+    FL_COLSUM(c & 1);
   }
 #undef FL_ISSUE
 #undef FL_PARK
@@ -358,7 +360,7 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
 #pragma unroll
   for (int r = 0; r < 16; ++r) *(lf1_t*)(mine + ((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + lr) = acc[r];
   if constexpr (TA) {
-    if (colsum) *(lf1_t*)(smem + 4 * TS * SLD + threadIdx.x) = cs;  // [8 row groups][32 columns], behind the partial tiles
+    if (colsum) *(lf1_t*)(smem + 4 * TS * SLD + tidx) = cs;  // [8 row groups][32 columns], behind the partial tiles
   }
   __syncthreads();
   const float* s0 = smem + er * SLD + ec;
@@ -368,11 +370,11 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
   float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
   const float gmul = jb.gate ? 1.f + fl::sigmoid_acc(e_gate) : 1.f;
   if constexpr (TA) {
-    if (colsum && threadIdx.x < TS) {  // FL_PG_TA requires M % 32 == 0: every row of the tile exists
+    if (colsum && tidx < TS) {  // FL_PG_TA requires M % 32 == 0: every row of the tile exists
       float t = 0.f;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) t += *(const lf1_t*)(smem + 4 * TS * SLD + g * TS + threadIdx.x);
-      st1g(wt, wp(jb.aux[0], io) + rt * TS + threadIdx.x, jb.alpha * gmul * t);
+      for (int g = 0; g < 8; ++g) t += *(const lf1_t*)(smem + 4 * TS * SLD + g * TS + tidx);
+      st1g(wt, wp(jb.aux[0], io) + rt * TS + tidx, jb.alpha * gmul * t);
     }
   }
   if (gr < jb.M) {
@@ -410,9 +412,10 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
 // four 32 x 32 tiles: half the operand traffic, no LDS round trip for the partial sums, 128 MFMAs per wave behind one
 // load latency instead of 32 (measured: 4.6 us per 32 x 32 tile -> 7 us per 64 x 64).
 __device__ __forceinline__ void wg64_tile(const fl_pjob& jb, int rt, int ct, const ProgIO& io, float* smem, const bool wt) {
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), w = w8 & 3;  // 8 waves load, waves 0-3 compute
   const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
   const int wr = w >> 1, wc = w & 1;
+  const bool compute = w8 < 4;
   const float* A0 = rp(jb.A[0], io) + rt * 64 + (lane & 15) * 4;
   const float* W0 = rp(jb.W[0], io) + ct * 64 + (lane & 15) * 4;
   const int K = jb.K[0], lda = jb.lda[0], ldw = jb.ldw[0];
@@ -429,10 +432,10 @@ __device__ __forceinline__ void wg64_tile(const fl_pjob& jb, int rt, int ct, con
   for (int kk = 0; kk < K; kk += 256) {
     const int kv = K - kk < 256 ? K - kk : 256;
     if (kk) __syncthreads();  // every wave has read the previous chunk
-    // wave w moves rows [64 w, 64 w + 64) of both images: 16 x (4 rows x 256 B) each; rows past the end re-read row K-1
+    // wave w8 moves rows [32 w8, 32 w8 + 32) of both images: 8 x (4 rows x 256 B) each; rows past the end re-read row K-1
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row4 = (w * 16 + q) * 4;
+    for (int q = 0; q < 8; ++q) {
+      const int row4 = (w8 * 8 + q) * 4;
       if (row4 < kv) {  // wave-uniform
         int kr = kk + row4 + (lane >> 4);
         kr = kr < K ? kr : K - 1;
@@ -447,7 +450,7 @@ __device__ __forceinline__ void wg64_tile(const fl_pjob& jb, int rt, int ct, con
       else if (threadIdx.x < 32) *(lf4_t*)(imgW + kv * 64 + (threadIdx.x - 16) * 4) = f32x4v{0.f, 0.f, 0.f, 0.f};
       __syncthreads();
     }
-    const int steps = (kv + 1) >> 1;
+    const int steps = compute ? (kv + 1) >> 1 : 0;
     const float* pa = imgA + lh * 64 + 32 * wr + lr;
     const float* pw = imgW + lh * 64 + 32 * wc + lr;
     int s = 0;
@@ -472,9 +475,11 @@ __device__ __forceinline__ void wg64_tile(const fl_pjob& jb, int rt, int ct, con
   }
   // C/D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   float* C = wp(jb.C, io) + (long long)(rt * 64 + 32 * wr + 4 * lh) * jb.ldc + ct * 64 + 32 * wc + lr;
+  if (compute) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) st1g(wt, C + (long long)((r & 3) + 8 * (r >> 2)) * jb.ldc, acc[r]);
-  if (colsum) {
+    for (int r = 0; r < 16; ++r) st1g(wt, C + (long long)((r & 3) + 8 * (r >> 2)) * jb.ldc, acc[r]);
+  }
+  if (colsum && compute) {
     cs += __shfl_xor(cs, 32, 64);
     const float gmul = jb.gate ? 1.f + fl::sigmoid_acc(e_gate) : 1.f;
     if (lh == 0) st1g(wt, wp(jb.aux[0], io) + rt * 64 + 32 * wr + lr, jb.alpha * gmul * cs);
@@ -499,104 +504,164 @@ __device__ __forceinline__ void wait_vm(int n) {
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
+// the workgroup barrier WITHOUT the memory fence of __syncthreads() (hipcc puts s_waitcnt vmcnt(0) lgkmcnt(0) in front of that
+// one: it would drain every DMA in flight). LDS reads of the waiting wave must have been consumed before (they feed MFMAs).
+__device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
 
-// The W side of a FL_PG_DMA job as the tile loop needs it: read from the job's LDS copy (a few words, wave-uniform), so the
-// NEXT tile's weights can be requested without holding a second descriptor in registers.
-// The W side of a FL_PG_DMA job is read from the job's LDS copy into LOCAL scalars (a struct or array whose members are
-// then picked by the chunk's segment would be kept in scratch memory: hipcc turns the select into an indexed load).
-__device__ __forceinline__ int lds_word(const int* job, int word) { return __builtin_amdgcn_readfirstlane(((ldsint_p)job)[word]); }
-__device__ __forceinline__ const float* lds_ptr(const int* job, int word) {
-  return reinterpret_cast<const float*>((uint64_t)(unsigned)lds_word(job, word) | ((uint64_t)(unsigned)lds_word(job, word + 1) << 32));
-}
-#define FL_LOAD_WSRC(P, job)                                                                         \
-  const float* P##W0 = lds_ptr(job, FL_JW(W));                                                       \
-  const float* P##W1 = lds_ptr(job, FL_JW(W) + 2);                                                   \
-  const float* P##W2 = lds_ptr(job, FL_JW(W) + 4);                                                   \
-  const int P##ldw0 = lds_word(job, FL_JW(ldw)), P##ldw1 = lds_word(job, FL_JW(ldw) + 1),            \
-            P##ldw2 = lds_word(job, FL_JW(ldw) + 2);                                                 \
-  const int P##nseg = lds_word(job, FL_JW(nseg));                                                    \
-  const int P##c1 = lds_word(job, FL_JW(K)) / DKC;                                                   \
-  const int P##c2 = P##nseg > 1 ? P##c1 + lds_word(job, FL_JW(K) + 1) / DKC : P##c1;                 \
-  const int P##nC = P##nseg > 2 ? P##c2 + lds_word(job, FL_JW(K) + 2) / DKC : P##c2;                 \
-  const bool P##tw = (lds_word(job, FL_JW(flags)) & FL_PG_TW) != 0
-#define FL_WSRC_ARGS(P) P##W0, P##W1, P##W2, P##ldw0, P##ldw1, P##ldw2, P##c1, P##c2, P##tw
+// Operand streams of a FL_PG_DMA job: up to three concatenated-K segments per operand, walked in 128-wide chunks.
+// (Local scalars, copied out of the descriptor BEFORE any select: a struct or array whose members are picked by a
+// computed segment index is kept in scratch memory by hipcc.)
+#define FL_DMA_SRC(P, J, IO)                                                                                       \
+  const int P##nseg = (J).nseg;                                                                                    \
+  const float* P##A0 = rp((J).A[0], IO);                                                                           \
+  const float* P##A1 = P##nseg > 1 ? rp((J).A[1], IO) : P##A0;                                                     \
+  const float* P##A2 = P##nseg > 2 ? rp((J).A[2], IO) : P##A0;                                                     \
+  const float* P##W0 = rp((J).W[0], IO);                                                                           \
+  const float* P##W1 = P##nseg > 1 ? rp((J).W[1], IO) : P##W0;                                                     \
+  const float* P##W2 = P##nseg > 2 ? rp((J).W[2], IO) : P##W0;                                                     \
+  const int P##lda0 = (J).lda[0], P##lda1 = (J).lda[1], P##lda2 = (J).lda[2];                                      \
+  const int P##ldw0 = (J).ldw[0], P##ldw1 = (J).ldw[1], P##ldw2 = (J).ldw[2];                                      \
+  const int P##c1 = (J).K[0] / DKC;                                                                                \
+  const int P##c2 = P##nseg > 1 ? P##c1 + (J).K[1] / DKC : P##c1;                                                  \
+  const int P##nC = P##nseg > 2 ? P##c2 + (J).K[2] / DKC : P##c2
+// chunk c of stream P: segment base pointers, leading dimensions, k offset inside the segment
+#define FL_DMA_CHUNK(P, c)                                                                                         \
+  const bool s1_ = (c) >= P##c1, s2_ = (c) >= P##c2;                                                               \
+  const float* Ab_ = s2_ ? P##A2 : (s1_ ? P##A1 : P##A0);                                                          \
+  const float* Wb_ = s2_ ? P##W2 : (s1_ ? P##W1 : P##W0);                                                          \
+  const int lda_ = s2_ ? P##lda2 : (s1_ ? P##lda1 : P##lda0), ldw_ = s2_ ? P##ldw2 : (s1_ ? P##ldw1 : P##ldw0);    \
+  const int kk_ = ((c) - (s2_ ? P##c2 : (s1_ ? P##c1 : 0))) * DKC;                                                 \
+  const int ncs_ = s2_ ? P##nC - P##c2 : (s1_ ? P##c2 - P##c1 : P##c1); /* chunks of the chunk's segment */           \
+  (void)Ab_; (void)lda_; (void)ncs_
 
-// W chunk c of column tile ct -> the W image of ring stage c % DSTAGES (4 LDS-DMA instructions per wave).
-//   not TW: W[n][k] rows n = 32 ct + 8 w + 2 i + (lane >> 5); lane fetches the 16-byte block j = (lane & 31) ^ (row & 15)
-//           of the chunk (row = 8 w + 2 i + (lane >> 5) inside the tile) and lands at block position lane & 31
-//   TW:     W[k][n] rows k = 32 w + 8 i + (lane >> 3) of the chunk, 128 B each: the image is [128 k][32 n], as it lies
-__device__ __forceinline__ void issue_w_chunk(const float* W0, const float* W1, const float* W2, int ldw0, int ldw1, int ldw2,
-                                              int c1, int c2, bool tw, int c, int ct, float* smem) {
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const bool s1 = c >= c1, s2 = c >= c2;
-  const float* Wb = s2 ? W2 : (s1 ? W1 : W0);
-  const int ldw = s2 ? ldw2 : (s1 ? ldw1 : ldw0);
-  const int kk = (c - (s2 ? c2 : (s1 ? c1 : 0))) * DKC;
-  float* img = smem + (c & (DSTAGES - 1)) * DSTAGE + DIMG;
-  if (tw) {
+// W chunk (base Wb, leading dimension ldw, k offset kk) of column tile ct -> W image `img`; lw = loader wave 0..3.
+//   not TW: W[n][k] rows n = 32 ct + 8 lw + 2 i + (lane >> 5); the lane fetches the 16-byte block j = (lane & 31) ^ (row & 15)
+//           of the chunk (row = 8 lw + 2 i + (lane >> 5) inside the tile) and lands at block position lane & 31
+//   TW:     W[k][n] rows k = 32 lw + 8 i + (lane >> 3) of the chunk, 128 B each: the image is [128 k][32 n], as it lies
+__device__ __forceinline__ void dma_w(const float* Wb, int ldw, int kk, int ct, bool tw, bool packed, int ncs, float* img, int lw,
+                                      int lane) {
+  if (packed) {  // FL_PG_WPACK: the chunk's image lies in memory as it will in LDS: 16 contiguous 1 KB pieces
+    const float* src = Wb + ((size_t)ct * ncs + (kk / DKC)) * DIMG + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + (8 * lw + 2 * i) * DKC), (lptr_t)(img + (8 * lw + 2 * i) * DKC), 16, 0, 0);
+  } else if (tw) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const unsigned off = __umul24((unsigned)(kk + 32 * w + 8 * i + (lane >> 3)), (unsigned)ldw) + (unsigned)(ct * TS + (lane & 7) * 4);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)off), (lptr_t)(img + (32 * w + 8 * i) * TS), 16, 0, 0);
+      const unsigned off = __umul24((unsigned)(kk + 32 * lw + 8 * i + (lane >> 3)), (unsigned)ldw) + (unsigned)(ct * TS + (lane & 7) * 4);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)off), (lptr_t)(img + (32 * lw + 8 * i) * TS), 16, 0, 0);
     }
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = 8 * w + 2 * i + (lane >> 5);
+      const int r = 8 * lw + 2 * i + (lane >> 5);
       const unsigned off = __umul24((unsigned)(ct * TS + r), (unsigned)ldw) + (unsigned)(kk + 4 * ((lane & 31) ^ (r & 15)));
-      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)off), (lptr_t)(img + (8 * w + 2 * i) * DKC), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)off), (lptr_t)(img + (8 * lw + 2 * i) * DKC), 16, 0, 0);
     }
   }
 }
 
-// Requests the first (up to 3) W chunks of the block's NEXT tile (pf_job = its descriptor in LDS; FL_PG_DMA | FL_PG_WCONST).
-// Ring stages 0..2 are free once every wave has left the current tile's loop; stage 3 holds the partial tiles meanwhile.
-// Returns the number of DMA instructions each wave issued (the caller's waits leave exactly these in flight).
-__device__ __forceinline__ int prefetch_w(const int* pf_job, int pf_ct, float* smem) {
-  FL_LOAD_WSRC(p_, pf_job);
-  const int n = p_nC < 3 ? p_nC : 3;
-  for (int c = 0; c < n; ++c) issue_w_chunk(FL_WSRC_ARGS(p_), c, pf_ct, smem);
-  return 4 * n;
-}
-
-// One 32 x 32 output tile of a FL_PG_DMA job. `pre`: DMA instructions per wave of THIS tile's first W chunks already in
-// flight (prefetch_w, issued before the preceding barrier / the previous tile's epilogue). pf_job != nullptr: the block's
-// next tile is a prefetchable GEMM (column tile pf_ct); returns what prefetch_w issued for it (0 if nothing).
+// One 32 x 32 output tile of a FL_PG_DMA job, run by the 512-thread block as 4 CONSUMER waves (0-3: fragment reads + MFMAs,
+// each its own 32-wide k slice of every chunk, then the partial tiles meet in LDS and the epilogue) and 4 LOADER waves (4-7:
+// every LDS-DMA instruction of the tile, 8 per wave and chunk). A DMA instruction costs its wave ~60-180 issue cycles that
+// nothing hides inside that wave; on a wave of its own it runs under the MFMAs of the consumer wave on the same SIMD.
+// Two rings (tools/dma_rate_probe.hip: a CU pulls 130-150 GB/s out of its XCD's L2 but only ~33 GB/s when every CU streams
+// from the Infinity Cache, which is where the weights of an XCD-local phase come from - every XCD reads all of them - while
+// the activations sit in L2): the W ring is 5 chunks deep and is filled for the block's NEXT tile as soon as this tile's
+// loop is over (the stream keeps running through the epilogue, the barrier and whatever row phase lies between two GEMM
+// phases), the A ring is 3 deep and filled behind the barrier that publishes the activations.
+// ONE raw s_barrier per chunk: passing barrier b means "chunk b has landed" (each loader waited for its own pieces with a
+// counted vmcnt) and "every consumer holds its fragments of chunk b - 1 in registers": its slots are refilled with A chunk
+// b + 2 and W chunk b + 4. Issue order of a loader wave (4 instructions per operand and chunk):
+//   [W_0..W_3 unless prefetched], A_0, A_1 | barrier 0 | A_2, W_4 | barrier 1 | A_3, W_5 | barrier 2 | ...
+// `pre` (loaders): DMA instructions of THIS tile's first W chunks already in flight (issued at the end of the block's
+// previous GEMM tile). prefetch: the block's next tile (descriptor image njw) is a prefetchable GEMM (column tile pf_ct).
+// Returns the DMA instructions the wave left in flight.
 template <bool TW>
-__device__ __forceinline__ int gemm_dma_tile(const fl_pjob& jb, int rt, int ct, const ProgIO& io, float* smem, const bool wt,
-                                             const int pre, const int* my_job, const int* pf_job, const int pf_ct) {
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+__device__ __forceinline__ int gemm_dma_tile(const jobwords_t jw, int rt, int ct, const ProgIO& io, float* smem, const bool wt,
+                                             const int pre, const jobwords_t& njw, const bool prefetch, const int pf_ct) {
+  fl_pjob jb;
+  load_job(jw, jb);
+  const int w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), w = w8 & 3;
   const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
-  FL_LOAD_WSRC(ws_, my_job);
-  const float* A0 = rp(jb.A[0], io);
-  const float *A1 = A0, *A2 = A0;
-  if (jb.nseg > 1) A1 = rp(jb.A[1], io);
-  if (jb.nseg > 2) A2 = rp(jb.A[2], io);
-  const int lda0 = jb.lda[0], lda1 = jb.lda[1], lda2 = jb.lda[2];
-  const int nC = ws_nC;
-  // A rows of this lane's four DMA instructions (clamped: rows past M repeat the last one, their results are never stored)
-  int arow[4], acol[4];
+  FL_DMA_SRC(m_, jb, io);
+  FL_STAMP(4);  // the descriptor is unpacked
+  const int nC = m_nC;
+  float* ringW = smem + NA * DIMG;
+  float* part = smem;  // the partial tiles meet in the A ring (free once the loop is over; the W ring takes the next tile's chunks)
+  if (w8 >= 4) {
+    // ------------------------------------------------------------------------------------------------ loader waves
+    int arow[4], acol[4];  // A rows of this lane's four DMA instructions (rows past M repeat the last one: never stored)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = 8 * w + 2 * i + (lane >> 5);
-    const int gr_ = rt * TS + r;
-    arow[i] = gr_ < jb.M ? gr_ : jb.M - 1;
-    acol[i] = 4 * ((lane & 31) ^ (r & 15));
-  }
-#define FL_ISSUE_A(cidx)                                                                               \
-  do {                                                                                                 \
-    const int c_ = (cidx);                                                                             \
-    const bool s1_ = c_ >= ws_c1, s2_ = c_ >= ws_c2;                                                   \
-    const float* Ab_ = s2_ ? A2 : (s1_ ? A1 : A0);                                                     \
-    const int lda_ = s2_ ? lda2 : (s1_ ? lda1 : lda0);                                                 \
-    const int kk_ = (c_ - (s2_ ? ws_c2 : (s1_ ? ws_c1 : 0))) * DKC;                                    \
-    float* img_ = smem + (c_ & (DSTAGES - 1)) * DSTAGE;                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                 \
-      const unsigned off_ = __umul24((unsigned)arow[i_], (unsigned)lda_) + (unsigned)(kk_ + acol[i_]); \
+    for (int i = 0; i < 4; ++i) {
+      const int r = 8 * w + 2 * i + (lane >> 5);
+      const int gr_ = rt * TS + r;
+      arow[i] = gr_ < jb.M ? gr_ : jb.M - 1;
+      acol[i] = 4 * ((lane & 31) ^ (r & 15));
+    }
+#define FL_LOAD_A(c, slot)                                                                               \
+  do {                                                                                                   \
+    FL_DMA_CHUNK(m_, c);                                                                                 \
+    (void)Wb_; (void)ldw_;                                                                               \
+    float* img_ = smem + (slot) * DIMG;                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
+      const unsigned off_ = __umul24((unsigned)arow[i_], (unsigned)lda_) + (unsigned)(kk_ + acol[i_]);   \
       __builtin_amdgcn_global_load_lds((gptr_t)(Ab_ + (size_t)off_), (lptr_t)(img_ + (8 * w + 2 * i_) * DKC), 16, 0, 0); \
-    }                                                                                                  \
+    }                                                                                                    \
   } while (0)
-
+#define FL_LOAD_W(c, slot)                                                                               \
+  do {                                                                                                   \
+    FL_DMA_CHUNK(m_, c);                                                                                 \
+    dma_w(Wb_, ldw_, kk_, ct, TW, wpack, ncs_, ringW + (slot) * DIMG, w, lane);                           \
+  } while (0)
+    const bool wpack = (jb.flags & FL_PG_WPACK) != 0;
+    const int npre = pre >> 2;  // W chunks already in flight (0..5)
+    for (int c = npre; c < 4 && c < nC; ++c) FL_LOAD_W(c, c);
+    FL_LOAD_A(0, 0);
+    if (nC > 1) FL_LOAD_A(1, 1);
+    // W_j is issued inside the loop (behind barrier j - 4) iff it exists and did not come with the prefetch
+#define FL_W_IN_LOOP(j) ((j) < nC && (j) >= npre && FL_PG_ABLATE != 2 && FL_PG_ABLATE != 5)
+#define FL_A_IN_LOOP(j) ((j) < nC && FL_PG_ABLATE != 3 && FL_PG_ABLATE != 5)
+    int sa = 2, sw = 4;  // ring slots of A chunk b + 2 / W chunk b + 4
+    for (int b = 0; b < nC; ++b) {
+      // DMA instructions issued after A_b (W_b is older than A_b): b = 0: A_1; b = 1: A_2, W_4; else W_(b+2), A_(b+1), W_(b+3)
+      int after;
+      if (b == 0) after = nC > 1 ? 4 : 0;
+      else if (b == 1) after = (FL_A_IN_LOOP(2) ? 4 : 0) + (FL_W_IN_LOOP(4) ? 4 : 0);
+      else after = (FL_W_IN_LOOP(b + 2) ? 4 : 0) + (FL_A_IN_LOOP(b + 1) ? 4 : 0) + (FL_W_IN_LOOP(b + 3) ? 4 : 0);
+      wait_vm(after);
+      raw_barrier();  // barrier b
+      if (FL_A_IN_LOOP(b + 2)) FL_LOAD_A(b + 2, sa);
+      if (FL_W_IN_LOOP(b + 4)) FL_LOAD_W(b + 4, sw);
+      sa = sa == NA - 1 ? 0 : sa + 1;
+      sw = sw == NW - 1 ? 0 : sw + 1;
+    }
+#undef FL_W_IN_LOOP
+#undef FL_A_IN_LOOP
+#undef FL_LOAD_A
+#undef FL_LOAD_W
+    raw_barrier();  // every consumer has left the loop: nothing is being read
+    raw_barrier();  // the partial tiles are written
+    raw_barrier();  // ... and read: the A ring is free again
+    // the next GEMM tile's first W chunks into the W ring (free since the loop ended), behind the tile's last barrier so that
+    // no consumer ever waits for this wave's issue slots; the stream runs on through the epilogue, the phase barrier and
+    // any row phase in between
+    int issued = 0;
+    if (prefetch) {
+      fl_pjob nj;  // (only the W side of the next tile's descriptor is unpacked)
+      load_job(njw, nj);
+      FL_DMA_SRC(n_, nj, io);
+      const bool ntw = (nj.flags & FL_PG_TW) != 0, npack = (nj.flags & FL_PG_WPACK) != 0;
+      const int n = n_nC < NW ? n_nC : NW;
+      for (int c = 0; c < n; ++c) {
+        FL_DMA_CHUNK(n_, c);
+        dma_w(Wb_, ldw_, kk_, pf_ct, ntw, npack, ncs_, ringW + c * DIMG, w, lane);
+      }
+      issued = 4 * n;
+    }
+    return issued;
+  }
+  // -------------------------------------------------------------------------------------------------- consumer waves
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -622,98 +687,73 @@ __device__ __forceinline__ int gemm_dma_tile(const fl_pjob& jb, int rt, int ct, 
   if (jb.R) e_r = ld4g(rp(jb.R, io) + (long long)grc * jb.ldr + gc);
   if (actbwd) e_p = ld4g(rp(jb.aux[1], io) + (long long)grc * jb.ld2 + gc);
   FL_STAMP(7);
-  // prologue: chunks 0..2. DMA instructions per wave and chunk: 8 (A + W), or 4 where the W half came with the prefetch
-  const int npre = pre >> 2;  // W chunks already in flight
-  const int n0 = nC < 3 ? nC : 3;
-  for (int c = 0; c < n0; ++c) {
-    FL_ISSUE_A(c);
-    if (c >= npre) issue_w_chunk(ws_W0, ws_W1, ws_W2, ws_ldw0, ws_ldw1, ws_ldw2, ws_c1, ws_c2, TW, c, ct, smem);
-  }
   FL_STAMP(8);
-  // instructions issued AFTER chunk c's (the wait at the top of iteration c leaves exactly those in flight)
-  int after1 = n0 > 1 ? (1 < npre ? 4 : 8) : 0, after2 = n0 > 2 ? (2 < npre ? 4 : 8) : 0;
-  for (int c = 0; c < nC; ++c) {
-    wait_vm(after1 + after2);
-    __syncthreads();  // chunk c has landed for every wave; every wave has left chunk c - 1 (its stage is free)
-#if FL_PROG_TRACE
-    if (c == 0) FL_STAMP(9);
-#endif
-    const float* Ia = smem + (c & (DSTAGES - 1)) * DSTAGE;
-    const float* Iw = Ia + DIMG;
-    f32x4v fa[4], fw[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int j = 8 * w + 4 * lh + q;  // 16-byte k block of this lane's fragment: k = 4 j + e
-      fa[q] = *(const lf4_t*)(Ia + lr * DKC + 4 * (j ^ (lr & 15)));
-      if constexpr (TW) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) fw[q][e] = *(const lf1_t*)(Iw + (4 * j + e) * TS + lr);
-      } else {
-        fw[q] = *(const lf4_t*)(Iw + lr * DKC + 4 * (j ^ (lr & 15)));
-      }
+  // fragments of chunk c + 1 are read (behind barrier c + 1) BEFORE the MFMAs of chunk c are issued: the LDS latency hides
+  // under 16 MFMAs. Passing barrier c + 1 also tells the loaders that every consumer holds chunk c in registers.
+  f32x4v fa[2][4], fw[2][4];
+#define FL_READ_FRAGS(c, set)                                                                           \
+  do {                                                                                                  \
+    const float* Ia_ = smem + ca * DIMG;                                                                \
+    const float* Iw_ = ringW + cw * DIMG;                                                               \
+    ca = ca == NA - 1 ? 0 : ca + 1;                                                                     \
+    cw = cw == NW - 1 ? 0 : cw + 1;                                                                     \
+    if (FL_PG_ABLATE == 4 && (c) > 0) break;                                                            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
+      const int j_ = 8 * w + 4 * lh + q_; /* 16-byte k block of this lane's fragment: k = 4 j + e */    \
+      fa[set][q_] = *(const lf4_t*)(Ia_ + lr * DKC + 4 * (j_ ^ (lr & 15)));                             \
+      if constexpr (TW) {                                                                               \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) fw[set][q_][e_] = *(const lf1_t*)(Iw_ + (4 * j_ + e_) * TS + lr); \
+      } else {                                                                                          \
+        fw[set][q_] = *(const lf4_t*)(Iw_ + lr * DKC + 4 * (j_ ^ (lr & 15)));                           \
+      }                                                                                                 \
+    }                                                                                                   \
+  } while (0)
+#define FL_MFMAS(set)                                                                                   \
+  do {                                                                                                  \
+    if (FL_PG_ABLATE == 1) break;                                                                       \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                  \
+      _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                  \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][q_][e_], fw[set][q_][e_], acc, 0, 0, 0);     \
+    }                                                                                                   \
+  } while (0)
+  int ca = 0, cw = 0;  // ring slots of the next chunk to read
+  raw_barrier();  // barrier 0: chunk 0 is in LDS
+  FL_STAMP(9);
+  FL_READ_FRAGS(0, 0);
+  for (int c = 0; c < nC; c += 2) {
+    if (c + 1 < nC) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      raw_barrier();  // barrier c + 1
+      FL_READ_FRAGS(c + 1, 1);
     }
-    const bool more = c + 3 < nC;  // block-uniform
-    if (more) {
-      // chunk c + 3 -> the stage chunk c - 1 has just left: one DMA instruction after every second MFMA (the matrix
-      // pipe is busy for 64 cycles per MFMA; a DMA issue is ~60-100)
-      const int c3 = c + 3;
-      const bool s1 = c3 >= ws_c1, s2 = c3 >= ws_c2;
-      const float* Ab = s2 ? A2 : (s1 ? A1 : A0);
-      const float* Wb = s2 ? ws_W2 : (s1 ? ws_W1 : ws_W0);
-      const int lda = s2 ? lda2 : (s1 ? lda1 : lda0), ldw = s2 ? ws_ldw2 : (s1 ? ws_ldw1 : ws_ldw0);
-      const int kk = (c3 - (s2 ? ws_c2 : (s1 ? ws_c1 : 0))) * DKC;
-      float* imgA = smem + (c3 & (DSTAGES - 1)) * DSTAGE;
-      float* imgW = imgA + DIMG;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][e], fw[q][e], acc, 0, 0, 0);
-          const int n = 4 * q + e;
-          if (n & 1) {
-            const int i = (n >> 1) & 3;
-            if (n < 8) {
-              const unsigned off = __umul24((unsigned)arow[i], (unsigned)lda) + (unsigned)(kk + acol[i]);
-              __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)off), (lptr_t)(imgA + (8 * w + 2 * i) * DKC), 16, 0, 0);
-            } else if constexpr (TW) {
-              const unsigned off = __umul24((unsigned)(kk + 32 * w + 8 * i + (lane >> 3)), (unsigned)ldw) + (unsigned)(ct * TS + (lane & 7) * 4);
-              __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)off), (lptr_t)(imgW + (32 * w + 8 * i) * TS), 16, 0, 0);
-            } else {
-              const int r = 8 * w + 2 * i + (lane >> 5);
-              const unsigned off = __umul24((unsigned)(ct * TS + r), (unsigned)ldw) + (unsigned)(kk + 4 * ((lane & 31) ^ (r & 15)));
-              __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)off), (lptr_t)(imgW + (8 * w + 2 * i) * DKC), 16, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
+    FL_MFMAS(0);
+    if (c + 1 < nC) {
+      if (c + 2 < nC) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        raw_barrier();  // barrier c + 2
+        FL_READ_FRAGS(c + 2, 0);
       }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][e], fw[q][e], acc, 0, 0, 0);
-      }
+      FL_MFMAS(1);
     }
-    after1 = after2;
-    after2 = more ? 8 : 0;
   }
-#undef FL_ISSUE_A
+#undef FL_READ_FRAGS
+#undef FL_MFMAS
   FL_STAMP(1);
-
-  // meet in LDS: sm[w][row][col] in ring stage 3 (stages 0..2 take the next tile's W chunks meanwhile); C/D layout of
-  // 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  __syncthreads();  // every wave has left the loop: no stage is being read
-  float* part = smem + 3 * DSTAGE;
+  raw_barrier();  // every consumer has left the loop
+  // meet in LDS: sm[w][row][col]; C/D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* mine = part + w * (TS * SLD);
 #pragma unroll
   for (int r = 0; r < 16; ++r) *(lf1_t*)(mine + ((r & 3) + 8 * (r >> 2) + 4 * lh) * SLD + lr) = acc[r];
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  raw_barrier();  // the partial tiles are written
   FL_STAMP(10);
   const float* s0 = part + er * SLD + ec;
   f32x4v vv = *(const lf4_t*)(s0);
 #pragma unroll
   for (int k = 1; k < 4; ++k) vv += *(const lf4_t*)(s0 + k * (TS * SLD));
   float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  raw_barrier();  // ... and read
   const float gmul = jb.gate ? 1.f + fl::sigmoid_acc(e_gate) : 1.f;
   if (gr < jb.M) {
 #pragma unroll
@@ -741,106 +781,135 @@ __device__ __forceinline__ int gemm_dma_tile(const fl_pjob& jb, int rt, int ct, 
     }
     st4g(wt, wp(jb.C, io) + (long long)gr * jb.ldc + gc, v);
   }
-  // the next tile's first W chunks: behind this tile's stores in issue order, so a counted wait on the stores leaves
-  // them in flight across the barrier
-  int issued = 0;
-  if (pf_job) issued = prefetch_w(pf_job, pf_ct, smem);
-  __syncthreads();  // the partial tiles (stage 3) are free again
-  return issued;
+  return 0;
 }
 
-// Row LayerNorm (+mask, act, residual, gated extra) and an optional second LayerNorm of the result; one wave per row.
-__device__ __forceinline__ void rownorm_tile(const fl_pjob& jb, int row4, const ProgIO& io, const bool wt) {
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int row = row4 + w;
-  if (row >= jb.M) return;
-  const int D = jb.N, nv = D >> 8;  // float4 per lane (D % 256 == 0, D <= 1024)
-  const float* x = rp(jb.A[0], io) + (long long)row * jb.lda[0];
-  float4 v[4];
+// Sum over the 64 lanes of a wave, the same value in every lane: four DPP steps (quad swaps, half-row and row mirrors: a
+// few cycles each) leave each 16-lane row's sum in all of its lanes, v_readlane picks the four row sums up. (The ds_bpermute
+// butterfly of __shfl_xor pays an LDS round trip per step: six dependent ~120-cycle hops per sum, four sums per LayerNorm pair.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wsum(float v) {  // needs all 64 lanes active
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+// nvq (1, 2 or 4) consecutive floats per lane
+struct f4a { float v[4]; };
+__device__ __forceinline__ f4a ldn(const float* p, int nvq) {
+  f4a r;
+  r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f;
+  if (nvq == 4) {
+    const float4 t = ld4g(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else if (nvq == 2) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    const f32x2v t = *(__attribute__((address_space(1))) const f32x2v*)(p);
+    r.v[0] = t[0]; r.v[1] = t[1];
+  } else {
+    r.v[0] = ld1g(p);
+  }
+  return r;
+}
+__device__ __forceinline__ void stn(bool wt, float* p, const f4a& x, int nvq) {
+  if (nvq == 4) {
+    st4g(wt, p, make_float4(x.v[0], x.v[1], x.v[2], x.v[3]));
+  } else {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (e < nvq) st1g(wt, p + e, x.v[e]);
+  }
+}
+
+// Row LayerNorm (+mask, act, residual, gated extra) and an optional second LayerNorm of the result: ONE ROW PER TILE, a
+// quarter row per wave (waves 0-3; the four quarter sums meet in LDS), so that the 32 rows of an XCD's row tile run on 32
+// CUs. One wave per row (four rows per tile, eight tiles per row tile) kept 24 of an XCD's 32 CUs idle while eight of them
+// pulled 128 KB each through a path that delivers ~45 GB/s per CU: ~9 us for the 1024-wide rows. Every operand of the row
+// is requested BEFORE the first reduction: one memory round trip per tile.
+// All 8 waves run the barriers (raw: no memory fence, the loaders' prefetch DMAs stay in flight).
+__device__ __forceinline__ float block4_sum(float v, float* slot, int w) {  // waves 0-3; `slot`: 4 floats of LDS, used once per tile
+  v = wsum(v);
+  if ((threadIdx.x & 63) == 0) *(lf1_t*)(slot + w) = v;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  raw_barrier();
+  return (*(const lf1_t*)(slot) + *(const lf1_t*)(slot + 1)) + (*(const lf1_t*)(slot + 2) + *(const lf1_t*)(slot + 3));
+}
+__device__ __forceinline__ void rownorm_tile(const fl_pjob& jb, int row_, const ProgIO& io, float* smem, const bool wt) {
+  const int w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const bool two = jb.W[1] != 0;
+  raw_barrier();  // the reduction slots of the block's previous tile have been read
+  if (w8 >= 4) {  // the loader waves only keep the barriers company
+    raw_barrier();
+    raw_barrier();
+    if (two) {
+      raw_barrier();
+      raw_barrier();
+    }
+    return;
+  }
+  const int w = w8;
+  const bool valid = row_ < jb.M;          // a ragged last row tile: compute on the last row, store nothing
+  const int row = valid ? row_ : jb.M - 1;
+  const int D = jb.N, nvq = D >> 8;        // floats per lane (D in {256, 512, 1024}: 1, 2, 4)
+  const int o = w * (D >> 2) + lane * nvq;
+  float* red = smem;                       // 16 floats at the start of ring stage 0's A image (no prefetch lands there)
+  const float* x = rp(jb.A[0], io) + (long long)row * jb.lda[0] + o;
+  const f4a v0 = ldn(x, nvq);
+  const f4a ww = ldn(rp(jb.W[0], io) + o, nvq), bb = ldn(rp(jb.bias[0], io) + o, nvq);
+  f4a km, rr, gg, ww2, bb2;
+  if (jb.mask) km = ldn(rp(jb.mask, io) + (long long)row * D + o, nvq);
+  if (jb.R) rr = ldn(rp(jb.R, io) + (long long)row * jb.ldr + o, nvq);
+  if (jb.gate) gg = ldn(rp(jb.aux[1], io) + (long long)row * jb.lda[1] + o, nvq);
+  if (two) {
+    ww2 = ldn(rp(jb.W[1], io) + o, nvq);
+    bb2 = ldn(rp(jb.bias[1], io) + o, nvq);
+  }
+  const float sg = jb.gate ? fl::sigmoid_acc(ld1g(rp(jb.gate, io))) : 0.f;
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < nv) {
-      v[i] = ld4g(x + (i * 64 + lane) * 4);
-      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
-  }
-  const float m = fl::wave_sum(s) / D;
+  for (int e = 0; e < 4; ++e)
+    if (e < nvq) s += v0.v[e];
+  const float m = block4_sum(s, red, w) / D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < nv) {
-      const float a = v[i].x - m, b = v[i].y - m, c = v[i].z - m, d = v[i].w - m;
-      q += (a * a + b * b) + (c * c + d * d);
-    }
-  }
-  const float r = 1.0f / sqrtf(fl::wave_sum(q) / D + jb.eps);
-  const float* w1 = rp(jb.W[0], io);
-  const float* b1 = rp(jb.bias[0], io);
-  const float* mk = jb.mask ? rp(jb.mask, io) + (long long)row * D : nullptr;
-  const float* R = jb.R ? rp(jb.R, io) + (long long)row * jb.ldr : nullptr;
-  const float* gx = jb.gate ? rp(jb.aux[1], io) + (long long)row * jb.lda[1] : nullptr;
-  const float sg = jb.gate ? fl::sigmoid_acc(ld1g(rp(jb.gate, io))) : 0.f;
-  float* y1 = jb.C ? wp(jb.C, io) + (long long)row * jb.ldc : nullptr;
+  for (int e = 0; e < 4; ++e)
+    if (e < nvq) q += (v0.v[e] - m) * (v0.v[e] - m);
+  const float r = 1.0f / sqrtf(block4_sum(q, red + 4, w) / D + jb.eps);
+  f4a y;
   float s2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < nv) {
-      const int o = (i * 64 + lane) * 4;
-      const float4 ww = ld4g(w1 + o), bb = ld4g(b1 + o);
-      float4 y;
-      y.x = (v[i].x - m) * r * ww.x + bb.x;
-      y.y = (v[i].y - m) * r * ww.y + bb.y;
-      y.z = (v[i].z - m) * r * ww.z + bb.z;
-      y.w = (v[i].w - m) * r * ww.w + bb.w;
-      if (mk) {
-        const float4 k = ld4g(mk + o);
-        y.x *= k.x; y.y *= k.y; y.z *= k.z; y.w *= k.w;
-      }
-      y.x = fl::apply_act(y.x, jb.act, 0.f);
-      y.y = fl::apply_act(y.y, jb.act, 0.f);
-      y.z = fl::apply_act(y.z, jb.act, 0.f);
-      y.w = fl::apply_act(y.w, jb.act, 0.f);
-      if (R) {
-        const float4 k = ld4g(R + o);
-        y.x += k.x; y.y += k.y; y.z += k.z; y.w += k.w;
-      }
-      if (gx) {
-        const float4 k = ld4g(gx + o);
-        y.x += sg * k.x; y.y += sg * k.y; y.z += sg * k.z; y.w += sg * k.w;
-      }
-      if (y1) st4g(wt, y1 + o, y);
-      v[i] = y;
-      s2 += (y.x + y.y) + (y.z + y.w);
+  for (int e = 0; e < 4; ++e) {
+    y.v[e] = 0.f;
+    if (e < nvq) {
+      float t = (v0.v[e] - m) * r * ww.v[e] + bb.v[e];
+      if (jb.mask) t *= km.v[e];
+      t = fl::apply_act(t, jb.act, 0.f);
+      if (jb.R) t += rr.v[e];
+      if (jb.gate) t += sg * gg.v[e];
+      y.v[e] = t;
+      s2 += t;
     }
   }
-  if (!jb.W[1]) return;
-  const float m2 = fl::wave_sum(s2) / D;
+  if (jb.C && valid) stn(wt, wp(jb.C, io) + (long long)row * jb.ldc + o, y, nvq);
+  if (!two) return;
+  const float m2 = block4_sum(s2, red + 8, w) / D;
   float q2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < nv) {
-      const float a = v[i].x - m2, b = v[i].y - m2, c = v[i].z - m2, d = v[i].w - m2;
-      q2 += (a * a + b * b) + (c * c + d * d);
-    }
-  }
-  const float r2 = 1.0f / sqrtf(fl::wave_sum(q2) / D + jb.eps2);
-  const float* w2 = rp(jb.W[1], io);
-  const float* b2 = rp(jb.bias[1], io);
-  float* y2 = wp(jb.aux[0], io) + (long long)row * jb.ldc;
+  for (int e = 0; e < 4; ++e)
+    if (e < nvq) q2 += (y.v[e] - m2) * (y.v[e] - m2);
+  const float r2 = 1.0f / sqrtf(block4_sum(q2, red + 12, w) / D + jb.eps2);
+  f4a z;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < nv) {
-      const int o = (i * 64 + lane) * 4;
-      const float4 ww = ld4g(w2 + o), bb = ld4g(b2 + o);
-      float4 y;
-      y.x = (v[i].x - m2) * r2 * ww.x + bb.x;
-      y.y = (v[i].y - m2) * r2 * ww.y + bb.y;
-      y.z = (v[i].z - m2) * r2 * ww.z + bb.z;
-      y.w = (v[i].w - m2) * r2 * ww.w + bb.w;
-      st4g(wt, y2 + o, y);
-    }
-  }
+  for (int e = 0; e < 4; ++e) z.v[e] = e < nvq ? (y.v[e] - m2) * r2 * ww2.v[e] + bb2.v[e] : 0.f;
+  if (valid) stn(wt, wp(jb.aux[0], io) + (long long)row * jb.ldc + o, z, nvq);
 }
 
 // elementwise kinds: tile k of the rows [r0, r1)
@@ -932,7 +1001,7 @@ __device__ __forceinline__ void ln_bwd_row(float4 (&v)[4], float4 (&g)[4], const
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     if (i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-  const float m = fl::wave_sum(s) / D;
+  const float m = wsum(s) / D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -941,7 +1010,7 @@ __device__ __forceinline__ void ln_bwd_row(float4 (&v)[4], float4 (&g)[4], const
       q += (a * a + b * b) + (c * c + d * d);
     }
   }
-  const float r = 1.0f / sqrtf(fl::wave_sum(q) / D + eps);
+  const float r = 1.0f / sqrtf(wsum(q) / D + eps);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -963,7 +1032,7 @@ __device__ __forceinline__ void ln_bwd_row(float4 (&v)[4], float4 (&g)[4], const
       s2 += (g[i].x * xh.x + g[i].y * xh.y) + (g[i].z * xh.z + g[i].w * xh.w);
     }
   }
-  const float t1 = fl::wave_sum(s1) / D, t2 = fl::wave_sum(s2) / D;
+  const float t1 = wsum(s1) / D, t2 = wsum(s2) / D;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (i < nv) {
@@ -1047,7 +1116,8 @@ __device__ __forceinline__ void lnbwd_tile(const fl_pjob& jb, int row4, const Pr
 // LayerNorm weight / bias gradients: 32 columns per tile. A lane owns 4 columns of every 32nd row (a wave's load covers
 // 8 rows x 128 B), the 32 row groups meet in an LDS tree. The row statistics are staged in LDS (coherent loads).
 __device__ __forceinline__ void lncol_tile(const fl_pjob& jb, int k, const ProgIO& io, float* smem, const bool wt) {
-  const int c4 = (threadIdx.x & 7) * 4, rg = threadIdx.x >> 3;
+  const int tidx = threadIdx.x & 255;  // waves 4-7 of the 512-thread block shadow waves 0-3 (same loads, same LDS words, same stores)
+  const int c4 = (tidx & 7) * 4, rg = tidx >> 3;
   const float* gl = rp(jb.A[0], io) + k * 32 + c4;
   const float* x = rp(jb.A[1], io) + k * 32 + c4;
   const float* st = rp(jb.aux[1], io);
@@ -1055,7 +1125,7 @@ __device__ __forceinline__ void lncol_tile(const fl_pjob& jb, int k, const ProgI
   for (int base = 0; base < jb.M; base += 1024) {
     const int rows = jb.M - base < 1024 ? jb.M - base : 1024;
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * rows; i += 256) *(lf1_t*)(smem + i) = ld1c(st + 2 * base + i);
+    for (int i = tidx; i < 2 * rows; i += 256) *(lf1_t*)(smem + i) = ld1c(st + 2 * base + i);
     __syncthreads();
 #pragma unroll 8
     for (int m = rg; m < rows; m += 32) {
@@ -1072,8 +1142,8 @@ __device__ __forceinline__ void lncol_tile(const fl_pjob& jb, int k, const ProgI
   *(lf4_t*)(smem + rg * 32 + c4) = t0;
   *(lf4_t*)(smem + 1024 + rg * 32 + c4) = t1;
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+  if (tidx < 64) {
+    const int which = tidx >> 5, c = tidx & 31;
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 32; ++g) t += *(const lf1_t*)(smem + which * 1024 + g * 32 + c);
@@ -1101,7 +1171,7 @@ __device__ __forceinline__ void loss_tile(const fl_pjob& jb, int row4, const Pro
       s += (d[i].x * d[i].x + d[i].y * d[i].y) + (d[i].z * d[i].z + d[i].w * d[i].w);
     }
   }
-  const float nrm = sqrtf(fl::wave_sum(s) + 1e-8f);
+  const float nrm = sqrtf(wsum(s) + 1e-8f);
   float dot = 0.f;
   float* out = wp(jb.C, io) + (long long)row * jb.ldc;
 #pragma unroll
@@ -1117,7 +1187,7 @@ __device__ __forceinline__ void loss_tile(const fl_pjob& jb, int row4, const Pro
       }
     }
   }
-  dot = fl::wave_sum(dot);
+  dot = wsum(dot);
   if (lane == 0) {
     st1g(wt, wp(jb.aux[0], io) + row, nrm);
     if (jb.aux[1]) st1g(wt, wp(jb.aux[1], io) + row, dot);
@@ -1125,9 +1195,10 @@ __device__ __forceinline__ void loss_tile(const fl_pjob& jb, int row4, const Pro
 }
 
 __device__ __forceinline__ float block_sum_lds(float v, float* smem) {
-  v = fl::wave_sum(v);
+  const int tidx = threadIdx.x & 255;  // waves 4-7 of the 512-thread block shadow waves 0-3 (same loads, same LDS words, same stores)
+  v = wsum(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) *(lf1_t*)(smem + (threadIdx.x >> 6)) = v;
+  if ((tidx & 63) == 0) *(lf1_t*)(smem + (tidx >> 6)) = v;
   __syncthreads();
   const float t = (*(const lf1_t*)(smem) + *(const lf1_t*)(smem + 1)) + (*(const lf1_t*)(smem + 2) + *(const lf1_t*)(smem + 3));
   __syncthreads();
@@ -1136,16 +1207,17 @@ __device__ __forceinline__ float block_sum_lds(float v, float* smem) {
 
 // loss = mean of the row norms; gradient of the residual gate = s(1-s) * sum of the row dots (gate_grad_kernel)
 __device__ __forceinline__ void fin_tile(const fl_pjob& jb, const ProgIO& io, float* smem, const bool wt) {
+  const int tidx = threadIdx.x & 255;  // waves 4-7 of the 512-thread block shadow waves 0-3 (same loads, same LDS words, same stores)
   float a = 0.f, b = 0.f;
   const float* n = rp(jb.A[0], io);
   const float* d = jb.A[1] ? rp(jb.A[1], io) : nullptr;
-  for (int i = threadIdx.x; i < jb.M; i += 256) {
+  for (int i = tidx; i < jb.M; i += 256) {
     a += ld1c(n + i);
     if (d) b += ld1c(d + i);
   }
   a = block_sum_lds(a, smem);
   b = block_sum_lds(b, smem);
-  if (threadIdx.x == 0) {
+  if (tidx == 0) {
     st1g(wt, wp(jb.C, io), a / jb.M);
     if (d) {
       const float sg = fl::sigmoid_acc(ld1g(rp(jb.gate, io)));
@@ -1209,11 +1281,12 @@ __device__ __forceinline__ void flat_slice(int n, int t, int& lo, int& hi) {
 }
 
 __device__ __forceinline__ void sqnorm_tile(const fl_pjob& jb, int t, const ProgIO& io, float* smem, const bool wt) {
+  const int tidx = threadIdx.x & 255;  // waves 4-7 of the 512-thread block shadow waves 0-3 (same loads, same LDS words, same stores)
   const float* g = rp(jb.A[0], io);
   int lo, hi;
   flat_slice(jb.K[0], t, lo, hi);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int i = lo + threadIdx.x * 4;
+  int i = lo + tidx * 4;
   for (; i + 3 * 1024 + 3 < hi; i += 4096) {  // four float4 in flight
     const float4 p = ld4g(g + i), q = ld4g(g + i + 1024), r = ld4g(g + i + 2048), u = ld4g(g + i + 3072);
     a0 += (p.x * p.x + p.y * p.y) + (p.z * p.z + p.w * p.w);
@@ -1226,13 +1299,14 @@ __device__ __forceinline__ void sqnorm_tile(const fl_pjob& jb, int t, const Prog
     a0 += (p.x * p.x + p.y * p.y) + (p.z * p.z + p.w * p.w);
   }
   const float tot = block_sum_lds((a0 + a1) + (a2 + a3), smem);
-  if (threadIdx.x == 0) st1g(wt, wp(jb.C, io) + t, tot);
+  if (tidx == 0) st1g(wt, wp(jb.C, io) + t, tot);
 }
 
 // clip_grad_norm_ + Adam / AdamW: adam_kernel of loss_optim.hip with the clip coefficient derived in every tile from
 // the SQNORM partials (the same 256 numbers summed in the same order: identical in every tile)
 __device__ __forceinline__ void adam_tile(const fl_pjob& jb, int t, const ProgIO& io, float* smem) {
-  const float part = ld1c(rp(jb.W[0], io) + threadIdx.x);  // FLAT_TILES == 256 threads
+  const int tidx = threadIdx.x & 255;  // waves 4-7 of the 512-thread block shadow waves 0-3 (same loads, same LDS words, same stores)
+  const float part = ld1c(rp(jb.W[0], io) + tidx);  // FLAT_TILES == 256 threads
   const float sq = block_sum_lds(part, smem);
   const float gs = jb.alpha;
   const float nrm = gs * sqrtf(sq);
@@ -1242,7 +1316,7 @@ __device__ __forceinline__ void adam_tile(const fl_pjob& jb, int t, const ProgIO
     const float cf = maxn / (nrm + 1e-6f);
     coef = cf < 1.f ? cf : 1.f;
   }
-  if (t == 0 && threadIdx.x == 0) {
+  if (t == 0 && tidx == 0) {
     if (jb.aux[2]) *(__attribute__((address_space(1))) float*)wp(jb.aux[2], io) = coef;
     if (jb.aux[3]) *(__attribute__((address_space(1))) float*)wp(jb.aux[3], io) = nrm;
   }
@@ -1273,7 +1347,8 @@ __device__ __forceinline__ void adam_tile(const fl_pjob& jb, int t, const ProgIO
     (Vv) = vi_;                                                  \
     (P) = pi_ - step_size * (mi_ / (sqrtf(vi_) / bc2s + eps));   \
   } while (0)
-  for (int i = lo + threadIdx.x * 4; i < hi; i += 2048) {  // two float4 of each of the four arrays in flight
+  if (threadIdx.x >= 256) return;  // the update is a read-modify-write: the shadow waves stop here (no barrier follows)
+  for (int i = lo + tidx * 4; i < hi; i += 2048) {  // two float4 of each of the four arrays in flight
     const bool two = i + 1024 < hi;
     const int j = two ? i + 1024 : i;
     float4 g0 = ld4g(g + i), p0 = ld4g(p + i), m0 = ld4g(m + i), v0 = ld4g(v + i);
@@ -1305,7 +1380,7 @@ static_assert(ABORT_WORD == FL_PROG_SYNC_ABORT_WORD, "abort word");
 // per wave (issued after the stores) stay in flight
 __device__ __forceinline__ void drain_stores(int pending) {
   wait_vm(pending);
-  __syncthreads();
+  __builtin_amdgcn_s_barrier();  // (not __syncthreads(): its fence would wait for the prefetch DMAs too)
 }
 
 // Device-wide barrier for a fully resident grid. Returns false if the run is dead (timeout here or in another block):
@@ -1314,12 +1389,10 @@ __device__ __forceinline__ void drain_stores(int pending) {
 __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, bool acquire, bool release, int pending, int* s_ok) {
   drain_stores(pending);
   if (threadIdx.x == 0) {
-    FL_STAMP(3);
     if (release) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop its own wait after buffer_wbl2)
     }
-    FL_STAMP(4);
     // Polling is relaxed (plain sc1 loads): an acquire per poll would invalidate the L2 on every iteration.
     __hip_atomic_fetch_add(&sync[(blockIdx.x & (NCTR - 1)) * CTR_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     FL_STAMP(5);
@@ -1346,8 +1419,10 @@ __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, bo
     if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *s_ok = ok;
   }
-  __syncthreads();
-  return *s_ok != 0;
+  // (raw barrier: __syncthreads() would make the loader waves wait for their prefetch DMAs here)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  raw_barrier();
+  return *(volatile int*)s_ok != 0;
 }
 
 // Barrier among the blocks of ONE XCD (between two local phases). There are no L2-side atomics to be had on this memory
@@ -1361,8 +1436,6 @@ __device__ __forceinline__ bool xcd_barrier(unsigned* sync, int xcc, int slot, i
   drain_stores(pending);
   unsigned* line = &sync[xcc * CTR_STRIDE + FLAG_OFF];
   if (threadIdx.x < 64) {
-    FL_STAMP(3);
-    FL_STAMP(4);
     if (threadIdx.x == 0) *(__attribute__((address_space(1))) unsigned*)(line + slot) = value;
     FL_STAMP(5);
     const int lane = threadIdx.x;
@@ -1388,12 +1461,46 @@ __device__ __forceinline__ bool xcd_barrier(unsigned* sync, int xcc, int slot, i
       *s_ok = ok;
     }
   }
-  __syncthreads();
-  return *s_ok != 0;
+  // (raw barrier: __syncthreads() would make the loader waves wait for their prefetch DMAs here)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  raw_barrier();
+  return *(volatile int*)s_ok != 0;
 }
 
 // ---------------------------------------------------------------------------------------------- tile dealing
-// a tile of the current phase as this block sees it
+// Per job, next to the descriptors in LDS: jinfo[j] = { nrt << 16 | per, tile_begin | swizzle << 31 | prefetchable << 30,
+// magic(per), magic(nrt) } with magic(d) = floor(2^32 / d) + 1 (0 for d = 1): n / d == umulhi(n, magic) for n, d < 2^16 -
+// an integer division by a run-time divisor is ~40 instructions, several of them per tile.
+// A phase's window = those words of its (<= 64) jobs, one per lane, read ONCE per phase; every dealing decision is then
+// v_readlane + scalar arithmetic (a dependent LDS read per field cost ~100 cycles each: 2 us per tile before).
+constexpr int JW = sizeof(fl_pjob) / 4;
+constexpr unsigned JI_SWZ = 1u << 31, JI_PF = 1u << 30, JI_TB = (1u << 30) - 1;
+struct Win {
+  int jb0, jb1, ntiles, flags;
+  int dimv, tbv, mperv, mnrtv;  // per lane: lane l holds the words of job jb0 + l
+};
+__device__ __forceinline__ int udiv_magic(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
+__device__ __forceinline__ void load_win(const int* lph, const int* ljinfo, int p, Win& w) {
+  const ldsint_p ph = (ldsint_p)(lph + 4 * p);
+  w.jb0 = __builtin_amdgcn_readfirstlane(ph[0]);
+  w.jb1 = __builtin_amdgcn_readfirstlane(ph[1]);
+  w.ntiles = __builtin_amdgcn_readfirstlane(ph[2]);
+  w.flags = __builtin_amdgcn_readfirstlane(ph[3]);
+  int j = w.jb0 + (int)(threadIdx.x & 63);
+  j = j < w.jb1 ? j : w.jb1 - 1;
+  typedef int i32x4v __attribute__((ext_vector_type(4)));
+  const i32x4v v = *((const __attribute__((address_space(3))) i32x4v*)ljinfo + j);
+  w.dimv = v[0];
+  w.tbv = v[1];
+  w.mperv = v[2];
+  w.mnrtv = v[3];
+}
+__device__ __forceinline__ unsigned win_mper(const Win& w, int j) { return (unsigned)__builtin_amdgcn_readlane(w.mperv, j - w.jb0); }
+__device__ __forceinline__ unsigned win_mnrt(const Win& w, int j) { return (unsigned)__builtin_amdgcn_readlane(w.mnrtv, j - w.jb0); }
+__device__ __forceinline__ int win_dim(const Win& w, int j) { return __builtin_amdgcn_readlane(w.dimv, j - w.jb0); }
+__device__ __forceinline__ unsigned win_tb(const Win& w, int j) { return (unsigned)__builtin_amdgcn_readlane(w.tbv, j - w.jb0); }
+
+// a tile of a phase as this block sees it
 struct Cur {
   int j;     // job index (-1: none)
   int t;     // local phases: tile index among the job's tiles of this XCD; device-wide phases: tile index in the phase
@@ -1401,24 +1508,19 @@ struct Cur {
   int cnt;   // local phases: tiles of this XCD in job j
 };
 struct Deal {
-  const int* lph;  // phases, LDS
-  const int* ljb;  // jobs, LDS
   int xcc, slot, nx, G;
 };
-constexpr int JW = sizeof(fl_pjob) / 4;
 
-__device__ __forceinline__ int job_word(const Deal& d, int j, int word) { return lds_word(d.ljb + j * JW, word); }
-
-// local phase: the first tile at or after (job j, XCD-tile t >= 0 given by the slot rule) that belongs to this block
-__device__ __forceinline__ Cur local_seek(const Deal& d, int j, int job_end, int base) {
+// local phase: the first tile at or after job j (given `base` tiles of this XCD in the earlier jobs) that belongs to this block:
+// XCD-tile t of a job runs on the block with slot == (base + t) % nx
+__device__ __forceinline__ Cur local_seek(const Deal& d, const Win& w, int j, int base) {
   Cur c;
-  for (; j < job_end; ++j) {
-    const int nrt = job_word(d, j, FL_JW(nrt)), per = job_word(d, j, FL_JW(per));
+  for (; j < w.jb1; ++j) {
+    const int dim = win_dim(w, j);
+    const int nrt = dim >> 16, per = dim & 0xFFFF;
     const int mine = nrt > d.xcc ? (nrt - d.xcc + NCTR - 1) / NCTR : 0;
     const int cnt = mine * per;
-    // XCD-tile t of this job runs on the block with slot == (base + t) % nx
-    int t = (d.slot - base) % d.nx;
-    t = t < 0 ? t + d.nx : t;
+    const int t = (d.slot - base) & (d.nx - 1);  // nx is a power of two (fl_program_run)
     if (t < cnt) {
       c.j = j; c.t = t; c.base = base; c.cnt = cnt;
       return c;
@@ -1428,93 +1530,93 @@ __device__ __forceinline__ Cur local_seek(const Deal& d, int j, int job_end, int
   c.j = -1; c.t = 0; c.base = base; c.cnt = 0;
   return c;
 }
-__device__ __forceinline__ Cur global_at(const Deal& d, int p, int t) {
+__device__ __forceinline__ Cur global_at(const Win& w, int t) {
   Cur c;
-  c.base = 0; c.cnt = 0; c.t = t;
-  const int job_begin = lds_word(d.lph + 4 * p, 0), job_end = lds_word(d.lph + 4 * p, 1), ntiles = lds_word(d.lph + 4 * p, 2);
-  if (t >= ntiles) {
-    c.j = -1;
-    return c;
-  }
-  int j = job_begin;
-  while (j + 1 < job_end && t >= job_word(d, j + 1, FL_JW(tile_begin))) ++j;
-  c.j = j;
+  c.base = 0; c.cnt = 0; c.t = t; c.j = -1;
+  if (t >= w.ntiles) return c;
+  // the job whose [tile_begin, ...) holds t: count the jobs of the phase that begin at or before t
+  const int lane = threadIdx.x & 63;
+  const bool le = lane < w.jb1 - w.jb0 && (int)((unsigned)w.tbv & JI_TB) <= t;
+  c.j = w.jb0 + __builtin_popcountll(__builtin_amdgcn_ballot_w64(le)) - 1;
   return c;
 }
-__device__ __forceinline__ Cur first_tile(const Deal& d, int p, bool local) {
-  if (local) return local_seek(d, lds_word(d.lph + 4 * p, 0), lds_word(d.lph + 4 * p, 1), 0);
-  return global_at(d, p, (int)blockIdx.x);
+__device__ __forceinline__ Cur first_tile(const Deal& d, const Win& w, bool local) {
+  if (local) return local_seek(d, w, w.jb0, 0);
+  return global_at(w, (int)blockIdx.x);
 }
-__device__ __forceinline__ Cur next_tile(const Deal& d, int p, bool local, const Cur& c) {
-  if (!local) return global_at(d, p, c.t + d.G);
+__device__ __forceinline__ Cur next_tile(const Deal& d, const Win& w, bool local, const Cur& c) {
+  if (!local) return global_at(w, c.t + d.G);
   if (c.t + d.nx < c.cnt) {
     Cur n = c;
     n.t = c.t + d.nx;
     return n;
   }
-  return local_seek(d, c.j + 1, lds_word(d.lph + 4 * p, 1), c.base + c.cnt);
+  return local_seek(d, w, c.j + 1, c.base + c.cnt);
 }
 // (row tile, tile inside the row tile) of a dealt tile
-__device__ __forceinline__ void tile_coords(const Deal& d, bool local, const Cur& c, int& rt, int& k) {
-  const int nrt = job_word(d, c.j, FL_JW(nrt)), per = job_word(d, c.j, FL_JW(per));
+__device__ __forceinline__ void tile_coords(const Deal& d, const Win& w, bool local, const Cur& c, int& rt, int& k) {
+  const int dim = win_dim(w, c.j);
+  const int nrt = dim >> 16, per = dim & 0xFFFF;
   if (local) {
-    const int rl = c.t / per;
+    const int rl = udiv_magic(c.t, win_mper(w, c.j));
     k = c.t - rl * per;
     rt = d.xcc + NCTR * rl;
     return;
   }
-  const int lt = c.t - job_word(d, c.j, FL_JW(tile_begin));
-  if (job_word(d, c.j, FL_JW(kind)) == FL_PJOB_GEMM && (per & 7) == 0) {
-    // tile lt runs on XCD lt%8 (round-robin block placement): keep a weight column block on one XCD
-    const int x = lt & 7, jj = lt >> 3, jc = jj / nrt;
+  const unsigned tb = win_tb(w, c.j);
+  const int lt = c.t - (int)(tb & JI_TB);
+  if (tb & JI_SWZ) {
+    // GEMM with a multiple of 8 column tiles: tile lt runs on XCD lt % 8 (round-robin block placement): keep a weight
+    // column block on one XCD
+    const int x = lt & 7, jj = lt >> 3, jc = udiv_magic(jj, win_mnrt(w, c.j));
     k = x + 8 * jc;
     rt = jj - jc * nrt;
   } else {
-    rt = lt / per;
+    rt = udiv_magic(lt, win_mper(w, c.j));
     k = lt - rt * per;
   }
 }
-__device__ __forceinline__ bool prefetchable(const Deal& d, const Cur& c) {
-  if (c.j < 0) return false;
-  const int need = FL_PG_DMA | FL_PG_WCONST;
-  return job_word(d, c.j, FL_JW(kind)) == FL_PJOB_GEMM && (job_word(d, c.j, FL_JW(flags)) & need) == need;
-}
+__device__ __forceinline__ bool prefetchable(const Win& w, const Cur& c) { return c.j >= 0 && (win_tb(w, c.j) & JI_PF) != 0; }
 
-// returns the prefetch DMA instructions per wave in flight for the block's next tile
-__device__ __forceinline__ int run_tile(const fl_pjob& jb, int rt, int k, const ProgIO& io, float* smem, const bool wt, const int pre,
-                                        const int* my_job, const int* pf_job, const int pf_ct) {
+// returns the prefetch DMA instructions the wave left in flight for the block's next tile
+__device__ __forceinline__ int run_tile(const jobwords_t jw, int rt, int k, const ProgIO& io, float* smem, const bool wt, const int pre,
+                                        const jobwords_t& njw, const bool prefetch, const int pf_ct) {
+  const int kind = ldsi(jw, FL_JW(kind)), flags = ldsi(jw, FL_JW(flags));
+  if (kind == FL_PJOB_GEMM && (flags & FL_PG_DMA)) {
+    if (flags & FL_PG_TW) return gemm_dma_tile<true>(jw, rt, k, io, smem, wt, pre, njw, prefetch, pf_ct);
+    return gemm_dma_tile<false>(jw, rt, k, io, smem, wt, pre, njw, prefetch, pf_ct);
+  }
+  fl_pjob jb;  // (each case reads the fields its tile uses: the rest of the unpacking is dead code there)
+  load_job(jw, jb);
   const int r0 = rt * TS, r1 = r0 + TS < jb.M ? r0 + TS : jb.M;
-  switch (jb.kind) {
+  const bool shadow = threadIdx.x >= 256;  // waves 4-7 only matter to the tiles that meet at workgroup barriers
+  switch (kind) {
     case FL_PJOB_GEMM:
-      if (jb.flags & FL_PG_DMA) {
-        if (jb.flags & FL_PG_TW) return gemm_dma_tile<true>(jb, rt, k, io, smem, wt, pre, my_job, pf_job, pf_ct);
-        return gemm_dma_tile<false>(jb, rt, k, io, smem, wt, pre, my_job, pf_job, pf_ct);
-      }
-      switch (jb.flags & (FL_PG_TA | FL_PG_TW)) {
+      switch (flags & (FL_PG_TA | FL_PG_TW)) {
         case 0: gemm_tile<false, false>(jb, rt, k, io, smem, wt); break;
         case FL_PG_TW: gemm_tile<false, true>(jb, rt, k, io, smem, wt); break;
         case FL_PG_TA | FL_PG_TW:
-          if (jb.flags & FL_PG_T64) wg64_tile(jb, rt, k, io, smem, wt);
+          if (flags & FL_PG_T64) wg64_tile(jb, rt, k, io, smem, wt);
           else gemm_tile<true, true>(jb, rt, k, io, smem, wt);
           break;
         default: break;  // TA alone: rejected by fl_program_job_tiles
       }
       break;
-    case FL_PJOB_ROWNORM: rownorm_tile(jb, r0 + 4 * k, io, wt); break;
-    case FL_PJOB_SINUSOID: sinusoid_tile(jb, r0, r1, k, io, wt); break;
-    case FL_PJOB_GATHER: gather_tile(jb, r0, r1, k, io, wt); break;
-    case FL_PJOB_PSAMPLE: psample_tile(jb, r0, r1, k, io, wt); break;
-    case FL_PJOB_LNBWD: lnbwd_tile(jb, r0 + 4 * k, io, wt); break;
+    case FL_PJOB_ROWNORM: rownorm_tile(jb, r0 + k, io, smem, wt); break;
+    case FL_PJOB_SINUSOID: if (!shadow) sinusoid_tile(jb, r0, r1, k, io, wt); break;
+    case FL_PJOB_GATHER: if (!shadow) gather_tile(jb, r0, r1, k, io, wt); break;
+    case FL_PJOB_PSAMPLE: if (!shadow) psample_tile(jb, r0, r1, k, io, wt); break;
+    case FL_PJOB_LNBWD: if (!shadow) lnbwd_tile(jb, r0 + 4 * k, io, wt); break;
     case FL_PJOB_LNCOL: lncol_tile(jb, k, io, smem, wt); break;
-    case FL_PJOB_LOSS: loss_tile(jb, r0 + 4 * k, io, wt); break;
+    case FL_PJOB_LOSS: if (!shadow) loss_tile(jb, r0 + 4 * k, io, wt); break;
     case FL_PJOB_FIN: fin_tile(jb, io, smem, wt); break;
-    case FL_PJOB_EWADD: ewadd_tile(jb, r0, r1, k, io, wt); break;
-    case FL_PJOB_EMBBWD: embbwd_tile(jb, k, io, smem, wt); break;
+    case FL_PJOB_EWADD: if (!shadow) ewadd_tile(jb, r0, r1, k, io, wt); break;
+    case FL_PJOB_EMBBWD: if (!shadow) embbwd_tile(jb, k, io, smem, wt); break;
     case FL_PJOB_SQNORM: sqnorm_tile(jb, k, io, smem, wt); break;
     case FL_PJOB_ADAM: adam_tile(jb, k, io, smem); break;
     default: break;
   }
-  return 0;
+  return pre;  // (a weight stream started for a later GEMM tile stays in flight across ring-safe tiles)
 }
 
 // Device-wide phases: any block may run any tile, outputs are stored write-through, the phase ends in the device-wide
@@ -1524,33 +1626,44 @@ __device__ __forceinline__ int run_tile(const fl_pjob& jb, int rt, int k, const 
 // own XCD's rows, data is handed from phase to phase through that XCD's L2 (plain stores, loads that hit L2 instead of
 // memory) and two local phases are separated by xcd_barrier among the 32 blocks of the XCD. Every XCD then streams all the
 // weights (8 x the weight traffic, out of the 256 MB Infinity Cache): the first weight chunks of a block's next tile are
-// requested BEFORE the barrier (gemm_dma_tile / prefetch_w).
-__global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __restrict__ phases, const fl_pjob* __restrict__ jobs,
+// requested BEFORE the barrier (gemm_dma_tile).
+// 512 threads: waves 4-7 are the LDS-DMA loaders of the GEMM tiles; the other tile kinds run on waves 0-3 (the loaders
+// shadow them where a tile meets at workgroup barriers, and skip the rest).
+__global__ __launch_bounds__(512, 1) void program_kernel(const fl_pphase* __restrict__ phases, const fl_pjob* __restrict__ jobs,
                                                          int nphases, int njobs, const ProgIO io, unsigned* sync, int allow_local) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_ok, s_slot;
   __shared__ unsigned s_epoch;
-  // the program lives in LDS for the whole run
+  // the program lives in LDS for the whole run: phases, jobs, jinfo
   int* lprog = reinterpret_cast<int*>(smem + 2 * STAGE);
+  const int nph_w = nphases * (int)(sizeof(fl_pphase) / 4);
+  int* ljobs = lprog + nph_w;
+  int* ljinfo = ljobs + njobs * JW;
   {
-    const int nph_w = nphases * (int)(sizeof(fl_pphase) / 4);
     const int* gp = reinterpret_cast<const int*>(phases);
-    for (int i = threadIdx.x; i < nph_w; i += 256) ((__attribute__((address_space(3))) int*)lprog)[i] = gp[i];
+    for (int i = threadIdx.x; i < nph_w; i += 512) ((__attribute__((address_space(3))) int*)lprog)[i] = gp[i];
     // jobs: 64-bit words; the leading pointer fields that name an io slot (1..FL_PROG_MAX_IO) are bound here, once,
     // so that no tile ever waits on a kernel-argument fetch
     constexpr int JQ = sizeof(fl_pjob) / 8, PTRQ = offsetof(fl_pjob, kind) / 8;
     const unsigned long long* gj = reinterpret_cast<const unsigned long long*>(jobs);
-    __attribute__((address_space(3))) unsigned long long* lj = (__attribute__((address_space(3))) unsigned long long*)(lprog + nph_w);
-    for (int i = threadIdx.x; i < njobs * JQ; i += 256) {
+    __attribute__((address_space(3))) unsigned long long* lj = (__attribute__((address_space(3))) unsigned long long*)ljobs;
+    for (int i = threadIdx.x; i < njobs * JQ; i += 512) {
       unsigned long long v = gj[i];
       if (i % JQ < PTRQ && v >= 1 && v <= FL_PROG_MAX_IO) v = reinterpret_cast<unsigned long long>(io.p[v - 1]);
       lj[i] = v;
     }
+    for (int j = threadIdx.x; j < njobs; j += 512) {
+      const fl_pjob& g = jobs[j];
+      const unsigned pf = (g.kind == FL_PJOB_GEMM && (g.flags & (FL_PG_DMA | FL_PG_WCONST)) == (FL_PG_DMA | FL_PG_WCONST)) ? JI_PF : 0u;
+      const unsigned swz = (g.kind == FL_PJOB_GEMM && (g.per & 7) == 0) ? JI_SWZ : 0u;
+      ((__attribute__((address_space(3))) int*)ljinfo)[4 * j] = (g.nrt << 16) | (g.per & 0xFFFF);
+      ((__attribute__((address_space(3))) int*)ljinfo)[4 * j + 1] = (int)((unsigned)g.tile_begin | swz | pf);
+      ((__attribute__((address_space(3))) int*)ljinfo)[4 * j + 2] = g.per > 1 ? (int)(0xFFFFFFFFu / (unsigned)g.per + 1u) : 0;
+      ((__attribute__((address_space(3))) int*)ljinfo)[4 * j + 3] = g.nrt > 1 ? (int)(0xFFFFFFFFu / (unsigned)g.nrt + 1u) : 0;
+    }
   }
   const unsigned G = gridDim.x;
   Deal d;
-  d.lph = lprog;
-  d.ljb = lprog + nphases * (int)(sizeof(fl_pphase) / 4);
   d.G = (int)G;
   d.xcc = 0;
   d.slot = 0;
@@ -1586,10 +1699,20 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
 #endif
   unsigned gbar = 0, lbar = 0;   // device-wide / XCD barriers passed so far
   bool dirty = false;            // plain-stored outputs since the last L2 write-back
-  int pre = 0;                   // prefetch DMAs per wave in flight for the next tile to run
-  bool have_first = false;       // `first` holds the first tile of the phase about to start
-  Cur first;
-  first.j = -1; first.t = 0; first.base = 0; first.cnt = 0;
+  int pre = 0;                   // (loader waves) prefetch DMAs in flight for the next tile to run
+  // the tile this block runs next, fully decoded: job descriptor in scalar registers, coordinates
+  Win cw, nw;
+  load_win(lprog, ljinfo, 0, cw);
+  nw = cw;
+  bool local = allow_local && (cw.flags & FL_PPHASE_LOCAL) != 0;
+  Cur cur = first_tile(d, cw, local);
+  bool have = cur.j >= 0;
+  jobwords_t jw = 0;  // the descriptor of `cur`, one word per lane
+  int rt = 0, k = 0;
+  if (have) {
+    jw = fetch_job(ljobs + cur.j * JW);
+    tile_coords(d, cw, local, cur, rt, k);
+  }
   for (int p = 0; p < nphases && alive; ++p) {
 #if FL_PROG_TRACE
     if (threadIdx.x == 0) {
@@ -1600,51 +1723,75 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
 #endif
     FL_STAMP(0);
 #if FL_PROG_TRACE
-    if (threadIdx.x == 0 && g_trace) g_trace[((size_t)blockIdx.x * g_trace_phases + g_trace_p) * 12 + 11] = clock64();
+    if (threadIdx.x == 0 && g_trace) g_trace[((size_t)blockIdx.x * g_trace_phases + g_trace_p) * 16 + 11] = clock64();
 #endif
-    const int pflags = lds_word(d.lph + 4 * p, 3);
-    const bool local = allow_local && (pflags & FL_PPHASE_LOCAL) != 0;
     const bool wt = !local;
     const bool has_next = p + 1 < nphases;
-    const int nflags = has_next ? lds_word(d.lph + 4 * (p + 1), 3) : 0;
-    const bool nlocal = has_next && allow_local && (nflags & FL_PPHASE_LOCAL) != 0;
-    Cur cur = have_first ? first : first_tile(d, p, local);
-    have_first = false;
-    while (cur.j >= 0) {
-      Cur nxt = next_tile(d, p, local, cur);
-      // what this block runs after `cur`: the phase's next tile, or the first tile of the next phase
+    if (has_next) load_win(lprog, ljinfo, p + 1, nw);
+    FL_STAMP(12);
+    const bool nlocal = has_next && allow_local && (nw.flags & FL_PPHASE_LOCAL) != 0;
+    bool carried = false;  // (cur, jw, rt, k) already describe this block's first tile of phase p + 1
+    while (have) {
+      const Cur nxt = next_tile(d, cw, local, cur);
+      // what this block runs after `cur`: the phase's next tile, or its first tile of the next phase
       Cur pf = nxt;
-      bool pf_local = local;
-      if (nxt.j < 0 && has_next) {
-        first = first_tile(d, p + 1, nlocal);
-        have_first = true;
-        pf = first;
-        pf_local = nlocal;
+      const bool pf_next = nxt.j < 0 && has_next;
+      if (pf_next) pf = first_tile(d, nw, nlocal);
+      const bool pf_ok = pf.j >= 0;
+      const bool pf_w = pf_ok && prefetchable(pf_next ? nw : cw, pf);
+      jobwords_t jwn = 0;
+      int nrt = 0, nk = 0;
+      if (pf_ok) {
+        tile_coords(d, pf_next ? nw : cw, pf_next ? nlocal : local, pf, nrt, nk);
+        jwn = fetch_job(ljobs + pf.j * JW);  // (an LDS read in flight: nothing waits for it before the tile's end)
       }
-      const int* pf_job = nullptr;
-      int pf_ct = 0;
-      if (prefetchable(d, pf)) {
-        int prt;
-        tile_coords(d, pf_local, pf, prt, pf_ct);
-        pf_job = d.ljb + pf.j * JW;
+      FL_STAMP(13);
+      // whose weights to stream once this tile's loop is over: the next tile's - or, from the block's last tile of a phase
+      // that is followed by a ring-safe phase (the row phase between two GEMM phases), its first tile of the phase after
+      bool pw = pf_w;
+      jobwords_t jwp = jwn;
+      int pk = nk;
+      if (!pw && nxt.j < 0 && p + 2 < nphases && (nw.flags & FL_PPHASE_RINGSAFE) != 0) {
+        Win w2;
+        load_win(lprog, ljinfo, p + 2, w2);
+        const bool local2 = allow_local && (w2.flags & FL_PPHASE_LOCAL) != 0;
+        const Cur t2 = first_tile(d, w2, local2);
+        if (prefetchable(w2, t2)) {
+          int prt;
+          tile_coords(d, w2, local2, t2, prt, pk);
+          jwp = fetch_job(ljobs + t2.j * JW);
+          pw = true;
+        }
       }
-      fl_pjob jb;
-      load_job(d.ljb + cur.j * JW, jb);
-      int rt, k;
-      tile_coords(d, local, cur, rt, k);
-      pre = run_tile(jb, rt, k, io, smem, wt, pre, d.ljb + cur.j * JW, pf_job, pf_ct);
-      cur = nxt;
+      FL_STAMP(3);  // the next tile(s) are dealt and their descriptors requested
+      pre = run_tile(jw, rt, k, io, smem, wt, pre, jwp, pw, pk);
+      have = nxt.j >= 0;
+      if (pf_ok) {
+        jw = jwn;
+        rt = nrt;
+        k = nk;
+        cur = pf;
+        carried = pf_next;
+      }
+    }
+    if (has_next && !carried) {  // (no tile here, or none left over: look the next phase's first tile up before the barrier)
+      cur = first_tile(d, nw, nlocal);
+      carried = cur.j >= 0;
+      if (carried) {
+        jw = fetch_job(ljobs + cur.j * JW);
+        tile_coords(d, nw, nlocal, cur, rt, k);
+      }
     }
     dirty = dirty || local;
     FL_STAMP(2);
 #if FL_PROG_TRACE
     if (threadIdx.x == 0 && g_trace) {
-      unsigned long long* e = &g_trace[((size_t)blockIdx.x * g_trace_phases + g_trace_p) * 12 + 11];
+      unsigned long long* e = &g_trace[((size_t)blockIdx.x * g_trace_phases + g_trace_p) * 16 + 11];
       *e = clock64() - *e;  // core-clock cycles spent on this phase's tiles
     }
 #endif
     if (has_next) {
-      const bool acq = (nflags & FL_PPHASE_ACQUIRE) != 0;
+      const bool acq = (nw.flags & FL_PPHASE_ACQUIRE) != 0;
       if (local && nlocal) {
         ++lbar;
         alive = xcd_barrier(sync, d.xcc, d.slot, d.nx, (epoch << 12) + lbar, acq, pre, &s_ok);
@@ -1653,6 +1800,9 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
         alive = grid_barrier(sync, gbar * G, acq, dirty, pre, &s_ok);
         dirty = false;
       }
+      cw = nw;
+      local = nlocal;
+      have = carried;
     }
     FL_STAMP(6);
   }
@@ -1672,11 +1822,25 @@ __global__ __launch_bounds__(256, 1) void program_kernel(const fl_pphase* __rest
       __hip_atomic_store(&sync[DEP_WORD], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       // every block has finished every phase: bump the per-run counters (step counter, Philox offset)
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
-        if (io.post.ptr64[k]) *(__attribute__((address_space(1))) long long*)(io.post.ptr64[k]) += io.post.delta64[k];
+      for (int kq = 0; kq < 2; ++kq)
+        if (io.post.ptr64[kq]) *(__attribute__((address_space(1))) long long*)(io.post.ptr64[kq]) += io.post.delta64[kq];
       if (io.post.ptr32) *(__attribute__((address_space(1))) int*)(io.post.ptr32) += io.post.delta32;
     }
   }
+}
+
+// FL_PG_WPACK image of a row-major weight (fl_program_pack_weight): one thread per 16-byte block of the output
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int N, int K, int ldw) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // output block index
+  const long long total = (long long)N * K / 4;
+  if (i >= total) return;
+  const int pb = (int)(i & 31);
+  const int r = (int)((i >> 5) & 31);
+  const long long tc = i >> 10;  // ct * nC + c
+  const int nC = K / DKC;
+  const int ct = (int)(tc / nC), c = (int)(tc - (long long)ct * nC);
+  const float* src = w + (size_t)(ct * TS + r) * ldw + c * DKC + 4 * (pb ^ (r & 15));
+  *reinterpret_cast<float4*>(out + i * 4) = *reinterpret_cast<const float4*>(src);
 }
 
 // tiles a job contributes: nrt row tiles x per tiles each; the kinds that are not laid out by row tiles count as ONE row tile
@@ -1686,7 +1850,7 @@ int row_tiles(const fl_pjob& jb) { return flat_kind(jb.kind) ? 1 : t64(jb) ? jb.
 int tiles_per_rowtile(const fl_pjob& jb) {
   switch (jb.kind) {
     case FL_PJOB_GEMM: return (jb.flags & FL_PG_T64) ? jb.N / 64 : jb.N / TS;
-    case FL_PJOB_ROWNORM:
+    case FL_PJOB_ROWNORM: return TS;  // one row per tile
     case FL_PJOB_LNBWD:
     case FL_PJOB_LOSS: return TS / 4;
     case FL_PJOB_SINUSOID: return (TS * (jb.N >> 1) + 255) / 256;
@@ -1757,7 +1921,7 @@ int fl_program_job_tiles(const void* job) {
                  "program ROWNORM: N=%d lda=%d ldc=%d", j.N, j.lda[0], j.ldc);
       FL_REQUIRE(!j.W[1] || (j.bias[1] && j.aux[0]), "program ROWNORM: second norm needs bias[1] and aux[0]");
       FL_REQUIRE(!j.gate || (j.aux[1] && j.lda[1] % 4 == 0), "program ROWNORM: gate needs aux[1]");
-      return ((j.M + TS - 1) / TS) * (TS / 4);
+      return ((j.M + TS - 1) / TS) * TS;
     case FL_PJOB_SINUSOID:
       FL_REQUIRE(j.A[0] && j.W[0] && j.N % 2 == 0, "program SINUSOID: N=%d", j.N);
       return ((j.M + TS - 1) / TS) * ((TS * (j.N / 2) + 255) / 256);
@@ -1816,7 +1980,7 @@ int fl_program_job_layout(void* job) {
   fl_pjob& j = *reinterpret_cast<fl_pjob*>(job);
   j.nrt = row_tiles(j);
   j.per = tiles_per_rowtile(j);
-  FL_REQUIRE(j.nrt * j.per == n, "program job: tile layout %d x %d != %d", j.nrt, j.per, n);
+  FL_REQUIRE(j.nrt * j.per == n && n < 65536 && j.nrt < 32768, "program job: tile layout %d x %d != %d (or >= 2^16 tiles)", j.nrt, j.per, n);
   j.flags &= ~FL_PG_DMA;
   if (j.kind == FL_PJOB_GEMM && !(j.flags & FL_PG_TA)) {
     bool ok = true;
@@ -1826,7 +1990,18 @@ int fl_program_job_layout(void* job) {
     }
     if (ok) j.flags |= FL_PG_DMA;
   }
+  FL_REQUIRE(!(j.flags & FL_PG_WPACK) || ((j.flags & FL_PG_DMA) && !(j.flags & FL_PG_TW)),
+             "program GEMM: FL_PG_WPACK needs an LDS-DMA job with W[n][k] operands (every K_s %% 128 == 0)");
   return n;
+}
+
+int fl_program_pack_weight(const float* w, float* out, int N, int K, int ldw, fl_stream_t stream) {
+  FL_REQUIRE(w && out && N >= TS && N % TS == 0 && K >= DKC && K % DKC == 0 && ldw >= K && ldw % 4 == 0 &&
+                 (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+             "fl_program_pack_weight: N=%d K=%d ldw=%d (N %% 32, K %% 128, 16-byte aligned operands)", N, K, ldw);
+  const long long blocks = ((long long)N * K / 4 + 255) / 256;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, out, N, K, ldw);
+  return fl::check_launch("pack_weight_kernel");
 }
 
 int fl_program_sync_bytes(void) { return SYNC_UINTS * 4; }
@@ -1835,7 +2010,7 @@ int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_job
                    void* sync, int max_blocks, int flags, const void* post, fl_stream_t stream) {
   FL_REQUIRE(phases && jobs && sync && n_phases >= 1 && n_jobs >= 1 && n_io >= 0 && n_io <= FL_PROG_MAX_IO && (n_io == 0 || io),
              "fl_program_run: bad args (n_phases=%d n_jobs=%d n_io=%d)", n_phases, n_jobs, n_io);
-  FL_REQUIRE((size_t)n_phases * sizeof(fl_pphase) + (size_t)n_jobs * sizeof(fl_pjob) <= (size_t)PROG_LDS_BYTES,
+  FL_REQUIRE((size_t)n_phases * sizeof(fl_pphase) + (size_t)n_jobs * (sizeof(fl_pjob) + 16) <= (size_t)PROG_LDS_BYTES,
              "fl_program_run: program too large for its LDS copy (%d phases, %d jobs; limit %d bytes)", n_phases, n_jobs,
              PROG_LDS_BYTES);
   ProgIO pio;
@@ -1859,8 +2034,9 @@ int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_job
   int G = cus;
   if (max_blocks > 0 && max_blocks < G) G = max_blocks;
   // local phases need the same number of blocks on every XCD (one block per CU: G / 8 each when G is the CU count)
-  const int allow_local = (flags & FL_PROG_XCD_LOCAL) != 0 && G == cus && G % NCTR == 0 && G / NCTR <= 32;
-  hipLaunchKernelGGL(program_kernel, dim3(G), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream),
+  const int nx = G / NCTR;
+  const int allow_local = (flags & FL_PROG_XCD_LOCAL) != 0 && G == cus && G % NCTR == 0 && nx <= 32 && (nx & (nx - 1)) == 0;
+  hipLaunchKernelGGL(program_kernel, dim3(G), dim3(512), LDS_BYTES, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const fl_pphase*>(phases), reinterpret_cast<const fl_pjob*>(jobs), n_phases, n_jobs, pio,
                      reinterpret_cast<unsigned*>(sync), allow_local);
   return fl::check_launch("program_kernel");

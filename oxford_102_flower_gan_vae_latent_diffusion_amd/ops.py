@@ -276,6 +276,14 @@ def pack_weight_f16x2(wp):
     return out
 
 
+def program_pack_weight(w, N, K, ldw, offset=0):
+    """[N][K] weight (row pitch ldw, starting `offset` floats into w) -> the tile-contiguous image FL_PG_WPACK jobs read."""
+    _chk(w)
+    out = torch.empty(N * K, dtype=torch.float32, device=w.device)
+    _lib.call("fl_program_pack_weight", ctypes.c_void_p(w.data_ptr() + 4 * offset), _p(out), N, K, ldw, _stream())
+    return out
+
+
 def f16x2_ok(x, Cout, kh, kw, stride, pad):
     B, H, W, Cin = x.shape
     return bool(_lib.load().fl_conv2d_fwd_f16x2_applicable(_p(x), B, H, W, Cin, Cout, kh, kw, stride, pad))

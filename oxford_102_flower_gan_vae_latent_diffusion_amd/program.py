@@ -16,7 +16,7 @@ from . import lib, ops
 import os
 
 GEMM, ROWNORM, SINUSOID, GATHER, PSAMPLE, LNBWD, LNCOL, LOSS, FIN, EWADD, EMBBWD, SQNORM, ADAM = range(13)
-PG_TA, PG_TW, PG_COLSUM, PG_ACTBWD, PG_DECOUPLED, PG_T64, PG_DMA, PG_WCONST = 1, 2, 4, 8, 16, 32, 64, 128
+PG_TA, PG_TW, PG_COLSUM, PG_ACTBWD, PG_DECOUPLED, PG_T64, PG_DMA, PG_WCONST, PG_WPACK = 1, 2, 4, 8, 16, 32, 64, 128, 256
 # XCD-local execution of the row-local phases (program.hip): on by default, FL_PROG_LOCAL=0 runs every phase device-wide
 LOCAL_DEFAULT = os.environ.get("FL_PROG_LOCAL", "1") != "0"
 ROW_KINDS = (GEMM, ROWNORM, SINUSOID, GATHER, PSAMPLE, LNBWD, LOSS, EWADD)  # row tile rt of the output needs row tile rt of the inputs
@@ -30,7 +30,8 @@ JOB_DTYPE = np.dtype([
     ("alpha", "<f4"), ("ld2", "<i4"), ("nrt", "<i4"), ("per", "<i4")])
 POST_DTYPE = np.dtype([("ptr64", "<u8", 2), ("delta64", "<i8", 2), ("ptr32", "<u8"), ("delta32", "<i4"), ("pad_", "<i4")])
 PHASE_DTYPE = np.dtype([("job_begin", "<i4"), ("job_end", "<i4"), ("ntiles", "<i4"), ("flags", "<i4")])
-PHASE_ACQUIRE, PHASE_LOCAL = 1, 2
+PHASE_ACQUIRE, PHASE_LOCAL, PHASE_RINGSAFE = 1, 2, 4
+RINGSAFE_KINDS = (ROWNORM, SINUSOID, GATHER, PSAMPLE, LNBWD, LOSS, EWADD)  # tiles that leave the GEMM tiles' LDS rings alone
 SYNC_ABORT_WORD = 8 * 1024 + 16
 
 
@@ -54,7 +55,10 @@ def _ptr(x, offset_elems=0):
 
 
 class ProgramBuilder:
-    def __init__(self):
+    def __init__(self, frozen_weights=False):
+        """frozen_weights: the weights do not change for the life of the program (inference): every eligible GEMM gets the
+        tile-contiguous packed copy of its weights (PG_WPACK)."""
+        self._frozen = frozen_weights
         self._phases = [[]]
         self._keep = []  # tensors whose storage the program points into
         self._wkeys = {}  # id(job array) -> buffers behind a GEMM job's W operands
@@ -94,16 +98,27 @@ class ProgramBuilder:
 
     def gemm(self, M, N, segs, C, ldc, biases=(), act=ops.ACT_NONE, R=None, ldr=0, mask=None, mask_group=0, gate=None,
              bias_row_index=None, bias_row_stride=0, ta=False, tw=False, colsum=None, colsum_alpha=1.0, actbwd=None,
-             ld_actbwd=0, pre_out=None, t64=False):
+             ld_actbwd=0, pre_out=None, t64=False, wpack=None):
         """C[M,N] = epi(sum_s A_s W_s^T). segs: [(A, lda, K, W, ldw)]; biases: [(bias, scale)]; with bias_row_index (a
         device int64) biases[0] is row *index of a table with row stride bias_row_stride.
         ta / tw: operand stored with the contraction index as its row (A[k][m], W[k][n]); colsum (needs ta): vector that
         receives colsum_alpha * (1 + sigmoid(gate)) * sum_k A[k][m]; actbwd: tensor P, the result is multiplied by
         act'(P[row][col]) instead of being activated; pre_out: also store the pre-activation value there; t64 (ta and tw,
-        M, N % 64 == 0, no epilogue): 64x64 tiles from one LDS stage (weight gradients)."""
+        M, N % 64 == 0, no epilogue): 64x64 tiles from one LDS stage (weight gradients). wpack: the weights are FROZEN
+        for the life of the program: every W_s is copied into the tile-contiguous image the LDS-DMA tile streams fastest
+        (N % 32 == 0, K_s % 128 == 0, not ta / tw)."""
+        wpack = self._frozen if wpack is None else wpack
+        if wpack and not (ta or tw) and N % 32 == 0 and all(K % 128 == 0 for _, _, K, _, _ in segs):
+            packed = []
+            for (A, lda, K, W, ldw) in segs:
+                Wt, off = (W if isinstance(W, tuple) else (W, 0))
+                packed.append((A, lda, K, ops.program_pack_weight(Wt, N, K, ldw, off), K))
+            segs = packed
+        else:
+            wpack = False
         j = np.zeros((), JOB_DTYPE)
         j["flags"] = (PG_TA if ta else 0) | (PG_TW if tw else 0) | (PG_COLSUM if colsum is not None else 0) | \
-            (PG_ACTBWD if actbwd is not None else 0) | (PG_T64 if t64 else 0)
+            (PG_ACTBWD if actbwd is not None else 0) | (PG_T64 if t64 else 0) | (PG_WPACK if wpack else 0)
         j["aux"][0], j["alpha"], j["aux"][1], j["ld2"], j["aux"][3] = _ptr(colsum), colsum_alpha, _ptr(actbwd), ld_actbwd, _ptr(pre_out)
         self._hold(colsum, actbwd, pre_out)
         j["kind"], j["M"], j["N"], j["nseg"] = GEMM, M, N, len(segs)
@@ -269,6 +284,8 @@ class ProgramBuilder:
                 stale |= set(w) & cached
             cached |= reads
             ph[pi]["job_begin"] = len(jobs)
+            if len(p) > 64:
+                raise ValueError("a phase holds %d jobs: the executor deals a phase from a 64-lane window of its jobs" % len(p))
             t0 = 0
             all_rows = local_ok
             for j, _, _ in p:
@@ -287,6 +304,8 @@ class ProgramBuilder:
                 all_rows = all_rows and kind in ROW_KINDS and not (kind == GEMM and flags & PG_TA) and int(j["M"]) == m_ref
             if all_rows:
                 ph[pi]["flags"] |= PHASE_LOCAL
+            if all(int(j["kind"]) in RINGSAFE_KINDS for j, _, _ in p):
+                ph[pi]["flags"] |= PHASE_RINGSAFE
             ph[pi]["job_end"], ph[pi]["ntiles"] = len(jobs), t0
             max_tiles = max(max_tiles, t0)
         jobs_np = np.stack(jobs)
@@ -502,7 +521,7 @@ class FoldedUNetProgram:
                                     ldb=Bm.shape[1])                                    # A @ Bm
         mv = lambda W, v, b=None: ops.linear(v.reshape(1, -1).contiguous(), W, b).reshape(-1)   # W v (+ b)
         keep = self.keep = []
-        pb = ProgramBuilder()
+        pb = ProgramBuilder(frozen_weights=True)
         with torch.no_grad():
             Wte2, bte2, Wce2, bce2 = d(te_m.lin2.weight), d(te_m.lin2.bias), d(ce_m.lin2.weight), d(ce_m.lin2.bias)
             bsum = (bte2 + bce2).contiguous()
@@ -626,7 +645,7 @@ class SamplerProgram:
             TE = un.time_emb(torch.arange(T, dtype=torch.int64, device=device))          # (T, E)
             ce = un.class_emb(c) if c is not None else None                              # (B, E)
             tb = 2.0 if c is not None else 1.0
-            pb = ProgramBuilder()
+            pb = ProgramBuilder(frozen_weights=True)
             self.keep = [TE, ce]
             mm = lambda A, Bm: ops.gemm(A.contiguous(), Bm.contiguous(), A.shape[0], Bm.shape[1], A.shape[1], b_layout=ops.KS,
                                         ldb=Bm.shape[1])                                    # A @ Bm

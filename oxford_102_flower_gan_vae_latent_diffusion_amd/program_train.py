@@ -21,40 +21,27 @@ from .program import IO, ProgramBuilder
 XT, T, CLS, EPS, BM0, HM0 = 0, 1, 2, 3, 4, 8  # IO slots
 
 
-class _Deferral:
-    """Weight gradients are off the backward's dependency chain (nothing reads them before the optimizer). The big ones
-    (>= 128 tiles of 64x64: the 1024-wide layer's) used to sit in the phase that produces their dy, next to that phase's
-    256 dgrad tiles - two heavy tiles per block, 25-29 us phases. They are cut into pieces of <= 128 tiles and each piece is
-    placed in the next later phase that leaves at least that many blocks idle (LayerNorm-backward rows, the narrow layers'
-    phases), where it is free; whatever is left runs in the last phase. Only whole idle blocks are used: the executor deals
-    tiles round-robin, so a phase is never filled past one tile per block by a deferred piece."""
+class _GlobalJobs:
+    """Jobs that contract over the BATCH (weight gradients with their bias column sums, LayerNorm weight / bias gradients, the
+    embedding gradient, the loss mean) need every row of the batch: they run device-wide. Nothing reads their outputs before
+    the optimizer, so they are queued here while the backward's row-local chain (input gradients, LayerNorm backward rows) is
+    laid out, and emitted as the program's LAST phase(s): the forward and the whole input-gradient chain then run XCD-local
+    (32 rows per XCD, data handed over through that XCD's L2), followed by ONE L2 write-back + device-wide barrier and one big
+    phase of ~2.8 k independent tiles. (Round 2 placed the weight gradients next to the input gradients of the same layer and
+    cut the largest into filler pieces for idle blocks: every one of its 54 phases was device-wide.)"""
 
-    def __init__(self, pb, blocks, piece_tiles=128):
-        self.pb, self.G, self.piece = pb, blocks, piece_tiles
-        self.q = []   # [emit(first_strip, n_strips), next_strip, strips, tiles_per_strip]
+    def __init__(self, pb):
+        self.pb, self.q = pb, []
 
-    def add(self, emit, strips, tiles_per_strip):
-        self.q.append([emit, 0, strips, tiles_per_strip])
+    def add(self, emit):
+        self.q.append(emit)
 
-    def _emit_piece(self):
-        emit, nxt, strips, per = job = self.q[0]
-        n = max(1, min(strips - nxt, self.piece // per))
-        emit(nxt, n)
-        job[1] += n
-        if job[1] >= strips:
-            self.q.pop(0)
-        return n * per
-
-    def end_phase(self, last=False, fill=True):
-        """fill=False: a phase of cheap element-wise tiles (a 7 us piece would more than double it)"""
-        if last:
-            while self.q:
-                self._emit_piece()
-        elif fill:
-            room = self.G - self.pb.tiles_in_phase()
-            while self.q and room >= min(self.piece, (self.q[0][2] - self.q[0][1]) * self.q[0][3]):
-                room -= self._emit_piece()
-        self.pb.barrier()
+    def flush(self, per_phase=64):
+        for i, emit in enumerate(self.q):
+            if i and i % per_phase == 0:
+                self.pb.barrier()
+            emit()
+        self.q = []
 
 
 class DenoiserTrainProgram:
@@ -75,25 +62,14 @@ class DenoiserTrainProgram:
         pb = ProgramBuilder()
         ws = self.ws = {}
 
-        props = torch.cuda.get_device_properties(device) if str(device).startswith("cuda") else None
-        dq = _Deferral(pb, props.multi_processor_count if props else 256)
-        defer_ok = [False]  # only inside the backward's layer loop (set below)
+        gq = _GlobalJobs(pb)
 
         def wgrad(dy, n_out, x, k_in, wname, bname=None, alpha=1.0, gate=None, w_off=0, b_off=0):
-            """dW[n_out, k_in] = dy^T x (+ bias gradient = alpha * column sums of dy) into the flat gradient buffer."""
+            """dW[n_out, k_in] = dy^T x (+ bias gradient = alpha * column sums of dy) into the flat gradient buffer (queued)."""
             t64 = n_out % 64 == 0 and k_in % 64 == 0
-
-            def emit(s0, ns):  # rows [64 s0, 64 (s0 + ns)) of the weight
-                m0 = 64 * s0
-                pb.gemm(64 * ns, k_in, [((dy, m0) if m0 else dy, n_out, B, x, k_in)], (G(wname), w_off + m0 * k_in), k_in,
-                        ta=True, tw=True, colsum=(G(bname), b_off + m0) if bname else None, colsum_alpha=alpha, gate=gate, t64=True)
-
-            if t64 and defer_ok[0] and (n_out // 64) * (k_in // 64) >= 128:
-                dq.add(emit, n_out // 64, k_in // 64)
-                return
-            pb.gemm(n_out, k_in, [(dy, n_out, B, x, k_in)], (G(wname), w_off) if w_off else G(wname), k_in, ta=True, tw=True,
-                    colsum=((G(bname), b_off) if b_off else G(bname)) if bname else None, colsum_alpha=alpha, gate=gate,
-                    t64=t64)
+            gq.add(lambda: pb.gemm(n_out, k_in, [(dy, n_out, B, x, k_in)], (G(wname), w_off) if w_off else G(wname), k_in, ta=True,
+                                   tw=True, colsum=((G(bname), b_off) if b_off else G(bname)) if bname else None,
+                                   colsum_alpha=alpha, gate=gate, t64=t64))
 
         def dgrad(dy, n_out, W, k_in, dx, **kw):
             """dx[B, k_in] = dy[B, n_out] W[n_out, k_in]"""
@@ -160,16 +136,15 @@ class DenoiserTrainProgram:
         pb.barrier()
 
         # ------------------------------------------------------------------ backward (engine.unet_backward)
-        defer_ok[0] = True
         dhf = new(B, Dl)
-        pb.fin(B, norms, self.loss, rowdot=rowdot, gate=rw, ggate=G("residual_weight"))
+        gq.add(lambda: pb.fin(B, norms, self.loss, rowdot=rowdot, gate=rw, ggate=G("residual_weight")))
         wgrad(dout, L, u, Dl, "final.weight", "final.bias", gate=rw)     # one weight, two uses: (1+sig) * column sums
         dgrad(dout, L, d(fin.weight), Dl, dhf)
-        dq.end_phase()
+        pb.barrier()
         dh, st_f = new(B, Dl), new(B, 2)
         pb.lnbwd(B, Dl, hpre, Dl, dhf, Dl, d(fn.weight), d(fn.bias), fn.eps, dh, Dl, stats=st_f)
-        dq.end_phase()
-        pb.lncol(B, Dl, dhf, Dl, hpre, Dl, st_f, G("final_norm.weight"), G("final_norm.bias"))
+        pb.barrier()
+        gq.add(lambda: pb.lncol(B, Dl, dhf, Dl, hpre, Dl, st_f, G("final_norm.weight"), G("final_norm.bias")))
         dte0, dce0 = new(B, E), new(B, E)
         wgrad(dh, Dl, te, E, "final_time_proj.weight", "final_time_proj.bias")
         wgrad(dh, Dl, ce, E, "final_class_proj.weight", "final_class_proj.bias")
@@ -188,51 +163,52 @@ class DenoiserTrainProgram:
             dh3 = new(B, D)
             wgrad(dh, Dn, h3, D, pre + "2.weight", pre + "2.bias")
             dgrad(dh, Dn, d(down.weight), D, dh3)
-            dq.end_phase()
+            pb.barrier()
             dv = new(B, D)
             wgrad(dh3, D, vm, D, ap + "out_proj.weight", ap + "out_proj.bias")
             dgrad(dh3, D, d(att.out_proj.weight), D, dv, mask=IO(HM0 + i) if masks else None, mask_group=D // att.num_heads)
-            dq.end_phase()
+            pb.barrier()
             dhn = new(B, D)
             # q/k rows of in_proj: exactly zero gradient (softmax over one key): never written, the buffer is zero there
             wgrad(dv, D, hn, D, ap + "in_proj_weight", ap + "in_proj_bias", w_off=2 * D * D, b_off=2 * D)
             dgrad(dv, D, (d(att.in_proj_weight), 2 * D * D), D, dhn)
-            dq.end_phase()
+            pb.barrier()
             # both LayerNorm backwards of the layer (v2:549 then v2:514-516) are row-local: one row job
             dh2, st_n, dg, gl, st_g = new(B, D), new(B, 2), new(B, D), new(B, D), new(B, 2)
             pb.lnbwd2(B, D, h2, dhn, d(norm.weight), d(norm.bias), norm.eps, dh3, dh2, st_n, g, d(ln.weight), d(ln.bias), ln.eps,
                       dg, act=SW, mask=IO(BM0 + i) if masks else None, gl=gl, stats=st_g)
-            dq.end_phase()
-            pb.lncol(B, D, dhn, D, h2, D, st_n, G(pre + "1.weight"), G(pre + "1.bias"))
+            pb.barrier()
+            gq.add(lambda dhn=dhn, h2=h2, st_n=st_n, pre=pre, D=D: pb.lncol(B, D, dhn, D, h2, D, st_n, G(pre + "1.weight"), G(pre + "1.bias")))
             dh1 = new(B, D)
             wgrad(dg, D, h1, D, pre + "0.0.weight", pre + "0.0.bias")
             dgrad(dg, D, d(lin.weight), D, dh1, R=dh2, ldr=D)
-            pb.lncol(B, D, gl, D, g, D, st_g, G(pre + "0.1.weight"), G(pre + "0.1.bias"))
-            dq.end_phase()
+            gq.add(lambda gl=gl, g=g, st_g=st_g, pre=pre, D=D: pb.lncol(B, D, gl, D, g, D, st_g, G(pre + "0.1.weight"), G(pre + "0.1.bias")))
+            pb.barrier()
             dtc_i = new(B, E)
             wgrad(dh1, D, tc, E, tpp + "weight", tpp + "bias", alpha=2.0)   # the bias enters twice (W te + b + W ce + b)
             dgrad(dh1, D, d(tp.weight), E, dtc_i, R=dtc, ldr=E)
             dtc = dtc_i
             dh = dh1
         wgrad(dh, un.layers[0][0][0].weight.shape[0], IO(XT), L, "latent_proj.weight", "latent_proj.bias")
-        dq.end_phase()
+        pb.barrier()
         dte, dce = new(B, E), new(B, E)
         pb.ewadd(B, E, dte0, dtc, dte)
         pb.ewadd(B, E, dce0, dtc, dce)
-        dq.end_phase(fill=False)
+        pb.barrier()
         d1t, d1c = new(B, H1), new(B, C1)
         wgrad(dte, E, te1a, H1, "time_emb.lin2.weight", "time_emb.lin2.bias")
         dgrad(dte, E, d(te_m.lin2.weight), H1, d1t, act=SW, actbwd=te1, ld_actbwd=H1)
         wgrad(dce, E, ce1a, C1, "class_emb.lin2.weight", "class_emb.lin2.bias")
         dgrad(dce, E, d(ce_m.lin2.weight), C1, d1c, act=SW, actbwd=ce1, ld_actbwd=C1)
-        dq.end_phase()
+        pb.barrier()
         demb = new(B, E)
         wgrad(d1t, H1, feat, E, "time_emb.lin1.weight", "time_emb.lin1.bias")
         wgrad(d1c, C1, emb, E, "class_emb.lin1.weight", "class_emb.lin1.bias")
         dgrad(d1c, C1, d(ce_m.lin1.weight), E, demb)
-        dq.end_phase()
-        pb.embbwd(B, E, n_cls, demb, IO(CLS), G("class_emb.embedding.weight"))
-        dq.end_phase(last=True)
+        pb.barrier()
+        pb.barrier()
+        gq.add(lambda: pb.embbwd(B, E, n_cls, demb, IO(CLS), G("class_emb.embedding.weight")))
+        gq.flush()
         self.prog = pb.finalize(device)
         self.out = out
         self._dummy = torch.zeros(4, **f32)

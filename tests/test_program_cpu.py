@@ -28,15 +28,15 @@ def test_tile_counts_and_phase_layout():
     a, w, c = torch.zeros(100, 64), torch.zeros(96, 64), torch.zeros(100, 96)
     x, g, b = torch.zeros(70, 512), torch.zeros(512), torch.zeros(512)
     pb.gemm(100, 96, [(a, 64, 64, w, 64)], c, 96)                      # ceil(100/32) * 96/32 = 12 tiles
-    pb.rownorm(70, 512, x, 512, g, b, 1e-5, torch.zeros(70, 512), 512)  # 3 row tiles x 8 = 24 tiles
+    pb.rownorm(70, 512, x, 512, g, b, 1e-5, torch.zeros(70, 512), 512)  # 3 row tiles x 32 rows = 96 tiles
     pb.barrier()
     pb.sinusoid(3, 256, torch.zeros(3, dtype=torch.int64), 1, torch.zeros(128), torch.zeros(3, 256), 256)  # 1 row tile x 16
     pb.gather(40, 256, torch.zeros(10, 256), 256, torch.zeros(40, dtype=torch.int64), torch.zeros(40, 256), 256)  # 2 row tiles x 8
     prog = pb.finalize("cpu")
     ph, jb = phases_of(prog), jobs_of(prog)
-    assert [tuple(p)[:3] for p in ph] == [(0, 2, 36), (2, 4, 32)]
-    assert list(jb["ntiles"]) == [12, 24, 16, 16] and list(jb["tile_begin"]) == [0, 12, 0, 16]
-    assert prog.max_tiles == 36 and prog.n_jobs == 4
+    assert [tuple(p)[:3] for p in ph] == [(0, 2, 108), (2, 4, 32)]
+    assert list(jb["ntiles"]) == [12, 96, 16, 16] and list(jb["tile_begin"]) == [0, 12, 0, 16]
+    assert prog.max_tiles == 108 and prog.n_jobs == 4
     assert not prog.local_ok and not prog.local  # jobs with different row counts: device-wide barriers only
 
 
@@ -170,44 +170,27 @@ def test_training_shape_rules_are_enforced(bad):
         pb.finalize("cpu")
 
 
-def test_weight_gradient_deferral_places_pieces_only_on_idle_blocks():
-    """program_train._Deferral (host logic): jobs are cut into pieces of <= 128 tiles, a piece goes into a phase only if
-    that many blocks are idle there, strips are emitted in order and everything left lands in the last phase."""
-    from oxford_102_flower_gan_vae_latent_diffusion_amd.program_train import _Deferral
-
-    class StubBuilder:
-        def __init__(self):
-            self.phase_tiles, self.closed = 0, []
-
-        def tiles_in_phase(self):
-            return self.phase_tiles
-
-        def barrier(self):
-            self.closed.append(self.phase_tiles)
-            self.phase_tiles = 0
-
-    pb = StubBuilder()
-    dq = _Deferral(pb, blocks=256, piece_tiles=128)
-    emitted = []
-
-    def mk(name, per):
-        def emit(s0, ns):
-            emitted.append((name, s0, ns))
-            pb.phase_tiles += ns * per
-        return emit
-
-    dq.add(mk("a", 16), 16, 16)     # 1024 x 1024: 16 strips of 16 tiles -> two pieces of 8 strips
-    dq.add(mk("b", 8), 16, 8)       # 1024 x 512: 16 strips of 8 tiles -> one piece
-    pb.phase_tiles = 256            # a full phase: nothing fits
-    dq.end_phase()
-    assert emitted == [] and pb.closed == [256]
-    pb.phase_tiles = 64             # 192 idle blocks: exactly one piece
-    dq.end_phase()
-    assert emitted == [("a", 0, 8)] and pb.closed[-1] == 192
-    pb.phase_tiles = 0              # an empty phase takes two pieces (256 blocks)
-    dq.end_phase()
-    assert emitted[1:] == [("a", 8, 8), ("b", 0, 16)] and pb.closed[-1] == 256
-    dq.add(mk("c", 16), 16, 16)
-    pb.phase_tiles = 200
-    dq.end_phase(last=True)         # the last phase takes whatever is left, in order
-    assert emitted[3:] == [("c", 0, 8), ("c", 8, 8)] and not dq.q
+def test_training_program_runs_the_row_local_chain_xcd_local_and_batch_contractions_last():
+    """program_train (host logic): the forward and the whole input-gradient chain are XCD-local phases; every job that
+    contracts over the batch (weight gradients, LayerNorm weight/bias gradients, embedding gradient, loss mean) sits in the
+    device-wide phase(s) at the very end, behind ONE local -> device-wide seam."""
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M, steps
+    from oxford_102_flower_gan_vae_latent_diffusion_amd.program_train import DenoiserTrainProgram
+    torch.manual_seed(0)
+    un = M.ConditionalUNet()
+    fp = steps.FlatParams(un, ("time_projections.4.", "attention_layers.4."))
+    tp = DenoiserTrainProgram(un, fp.gviews, 64, "cpu")
+    ph, jb = phases_of(tp.prog), jobs_of(tp.prog)
+    local = [bool(f & P.PHASE_LOCAL) for f in ph["flags"]]
+    n_global = local[::-1].index(True)          # trailing device-wide phases
+    assert 1 <= n_global <= 2 and all(local[:len(local) - n_global]) and tp.prog.n_local_phases == len(local) - n_global
+    row_kinds, batch_kinds = set(), set()
+    for pi, p in enumerate(ph):
+        for j in jb[p["job_begin"]:p["job_end"]]:
+            key = (int(j["kind"]), bool(j["flags"] & P.PG_TA))
+            (row_kinds if local[pi] else batch_kinds).add(key)
+    assert batch_kinds == {(P.GEMM, True), (P.LNCOL, False), (P.EMBBWD, False), (P.FIN, False)}
+    assert not (row_kinds & batch_kinds) and all(len(range(p["job_begin"], p["job_end"])) <= 64 for p in ph)
+    # every input-gradient GEMM of the chain takes the LDS-DMA tile and may stream its (constant) weights ahead
+    dg = [j for j in jb if j["kind"] == P.GEMM and j["flags"] & P.PG_TW and not j["flags"] & P.PG_TA]
+    assert dg and all(j["flags"] & P.PG_DMA and j["flags"] & P.PG_WCONST for j in dg)

@@ -32,7 +32,7 @@ else:
     up = P.UNetProgram(un, B, dev)
 nph = up.prog.n_phases
 G = torch.cuda.get_device_properties(0).multi_processor_count
-trace = torch.zeros(G * nph * 12, dtype=torch.int64, device=dev)
+trace = torch.zeros(G * nph * 16, dtype=torch.int64, device=dev)
 out = torch.empty(B, 256, device=dev)
 
 
@@ -55,7 +55,7 @@ trace.zero_()   # stamps a tile kind does not write stay 0 = "missing" below
 run()
 torch.cuda.synchronize()
 up.prog.check()
-tr = trace.view(G, nph, 12).cpu().double() * 0.01  # us
+tr = trace.view(G, nph, 16).cpu().double() * 0.01  # us
 print("program: %d phases, %d of them XCD-local (FL_PROG_LOCAL=%s)" % (nph, up.prog.n_local_phases, os.environ.get("FL_PROG_LOCAL", "1")))
 t0 = tr[:, 0, 0].min()
 print("blocks %d phases %d; total %.1f us (first phase start -> last phase tiles done)" % (G, nph, tr[:, nph - 1, 2].max() - t0))
@@ -74,8 +74,8 @@ for p in range(nph):
     m1 = act & (tr[:, p, 1] > 0)
     mf = (tr[m1, p, 1] - s[m1]).mean() if m1.any() else float("nan")
     if p + 1 < nph:
-        fence = (tr[:, p, 4] - tr[:, p, 3]).mean()
-        atom = (tr[:, p, 5] - tr[:, p, 4]).mean()
+        fence = float("nan")
+        atom = float("nan")
         spin = (tr[:, p, 6] - tr[:, p, 5]).mean()
         lastarr = tr[:, p, 5].max() - t0
     else:
@@ -86,12 +86,17 @@ for p in range(nph):
         det = " ptrs %.2f issue %.2f loop %.2f epi %.2f (%d blocks; last tile of each)" % (
             (tr[a, p, 7] - s[a]).mean(), (tr[a, p, 8] - tr[a, p, 7]).mean(), (tr[a, p, 1] - tr[a, p, 8]).mean(),
             (tr[a, p, 2] - tr[a, p, 1]).mean(), int(a.sum()))
+        one = a & (tr[:, p, 3] > s) & (tr[:, p, 4] > 0)
+        if one.any():  # (of the block's last tile: dealing + descriptor requests; unpacking; epilogue-operand requests)
+            det += " {deal %.2f (window %.2f, next tile %.2f, look-ahead %.2f) unpack %.2f operands %.2f}" % (
+                (tr[one, p, 3] - s[one]).mean(), (tr[one, p, 12] - s[one]).mean(), (tr[one, p, 13] - tr[one, p, 12]).mean(),
+                (tr[one, p, 3] - tr[one, p, 13]).mean(), (tr[one, p, 4] - tr[one, p, 3]).mean(), (tr[one, p, 7] - tr[one, p, 4]).mean())
         b = a & (tr[:, p, 9] > 0) & (tr[:, p, 10] > 0)    # LDS-DMA tiles: first chunk landed, partial tiles merged
         if b.any():
             det += " [first chunk %.2f, chunks %.2f, merge %.2f, epilogue+prefetch %.2f]" % (
                 (tr[b, p, 9] - tr[b, p, 8]).mean(), (tr[b, p, 1] - tr[b, p, 9]).mean(), (tr[b, p, 10] - tr[b, p, 1]).mean(),
                 (tr[b, p, 2] - tr[b, p, 10]).mean())
-    cyc = trace.view(G, nph, 12)[act, p, 11].double().cpu()
+    cyc = trace.view(G, nph, 16)[act, p, 11].double().cpu()
     mhz = (cyc / (tiles_done[act] - s[act])).mean()
     print("%-5d %8.2f %8.2f | %8.2f %8.2f %8.2f %8.2f %8.2f | %d tiles%s  clk %.0f MHz" % (p, start, end - start, tile_t, mf, fence, atom, spin, ntiles, det, mhz))
 
@@ -118,8 +123,8 @@ for p in range(nph - 1):
         continue
     tile_end = tr[:, p, 2]
     slow = int(torch.argmax(torch.where(ran, tile_end, torch.full_like(tile_end, -1e30))))
-    drain_mean = (tr[ran, p, 3] - tr[ran, p, 2]).mean()
-    drain_slow = tr[slow, p, 3] - tr[slow, p, 2]
+    drain_mean = (tr[ran, p, 5] - tr[ran, p, 2]).mean()
+    drain_slow = tr[slow, p, 5] - tr[slow, p, 2]
     last_arrive = tr[:, p, 5].max()
     first_leave, last_leave = tr[:, p, 6].min(), tr[:, p, 6].max()
     nxt = tr[:, p + 1, 0].min()
