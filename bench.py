@@ -404,6 +404,24 @@ def cpu_baseline(threads, quick=False):
                 median_s=top["median_s"], min_s=top["min_s"], per_config=per)
 
 
+def _self_launch(n):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same arguments> as a child process; returns
+    its exit code. Rendezvous on 127.0.0.1 (the container hostname may not resolve) at a free port."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / tensor sharing across processes needs it on this driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: starting %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -424,12 +442,17 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started like the 1-GPU case (`python bench.py --gpus N`): start the N ranks ourselves. Decided BEFORE anything in
+        # this process touches the GPU (a process that has initialised HIP must never re-exec): the ranks are children of a
+        # parent that only waits; rank 0's JSON line is the parent's stdout.
+        raise SystemExit(_self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or unset "
+                         "WORLD_SIZE and let bench.py start its ranks)" % (a.gpus, world, a.gpus))
     # rehearsal knobs (1-GPU boxes): FL_DIST_BACKEND=gloo + FL_SHARE_DEVICE=1 run all ranks on cuda:0 over gloo
     backend = os.environ.get("FL_DIST_BACKEND", "nccl")
     if os.environ.get("FL_SHARE_DEVICE"):
@@ -543,6 +566,12 @@ def main():
     if tr.persistent:
         tr.check_programs()   # a timed-out device-wide barrier would have voided the timed steps: raise instead of reporting
     log("timed region: %d steps in %.3f s (loss %.4f); host enqueue %.3f ms/step" % (a.steps, dt, final_loss, 1e3 * t_enq / a.steps))
+    comm = None
+    if world > 1 or os.environ.get("FL_FORCE_DP_OVERLAP") == "1":
+        # after the timed region: what the collective costs alone and how much of it the schedule leaves exposed
+        # (HIP events on the compute stream around the pieces of ten more steps), so that a scaling run explains itself
+        comm = tr.measure_comm(batches, labels, steps_n=10, overlapped=dp_overlap)
+        log("all-reduce alone %.3f ms; exposed per step %.3f ms" % (comm["allreduce_ms"], comm["allreduce_exposed_ms"]))
 
     out = {
         "metric": "images/sec VAE+UNet train step, 64x64 bs256",
@@ -571,6 +600,8 @@ def main():
             "gemm_math": gemm_math_note,
         },
     }
+    if comm is not None:
+        out["comm"] = comm
     if rank == 0 and world == 1:
         if not a.no_roofline:
             groups = measure_dominant_kernel(dev, B)

@@ -324,7 +324,9 @@ int fl_sqnorm(const float* x, int64_t n, float* out, int accumulate, void* ws, s
 int fl_clip_coef(const float* sqnorm, float max_norm, float* coef, float* norm_out, fl_stream_t stream); /* v2:1128,1263 */
 int fl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, const int32_t* step_dev,
                  float b1, float b2, float eps, float wd, const float* coef_dev, float gscale, int decoupled,
-                 fl_stream_t stream);                                                        /* v2:1026,1028,1247 */
+                 const float* betas_dev, fl_stream_t stream);                                /* v2:1026,1028,1247 */
+/* betas_dev != NULL: (beta1, beta2) are read from device memory instead of b1, b2 - a scheduler that cycles beta1 every batch
+ * (torch's OneCycleLR, v2:1031-1037) then also drives a step that was captured in a hipGraph */
 int fl_kl_fwd(const float* mu, const float* logvar, float* kl_row, float* musq_row, float* loss, int B, int D,
               fl_stream_t stream);                                                                    /* v2:380-386 */
 int fl_kl_bwd(const float* mu, const float* logvar, const float* kl_row, float gscale, const float* gdev, float* dmu,
@@ -432,7 +434,7 @@ int fl_reparam_bwd(const float* dz, const float* logvar, const float* eps, float
  *   FL_PJOB_ADAM     clip_grad_norm_ + Adam/AdamW (torch semantics) on the flat buffers: every tile sums the 256 partials
  *                    W[0] -> norm = alpha*sqrt(.), coef = min(1, bias_scale[2]/(norm+1e-6)); g' = g*alpha*coef; step =
  *                    *(int*)W[2] + 1 (bump it with fl_program_post); p = C, g = A[0], m = aux[0], v = aux[1], lr = *W[1],
- *                    b1, b2 = bias_scale[0..1], eps, weight decay = eps2 (decoupled iff flags & FL_PG_DECOUPLED);
+ *                    b1, b2 = bias_scale[0..1] (or, when bias[0] != 0, the two device floats it points to), eps, weight decay = eps2 (decoupled iff flags & FL_PG_DECOUPLED);
  *                    tile 0 stores coef -> aux[2], norm -> aux[3].
  * GEMM jobs may pick bias[0] from a table: when aux[2] != 0 the row *(int64*)aux[2] of stride bias_row_stride is
  * used (time-dependent terms of the sampler, precomputed for every timestep).
@@ -514,7 +516,9 @@ int fl_program_sync_bytes(void);
 #define FL_PROG_XCD_LOCAL 1 /* flags: honour FL_PPHASE_LOCAL (without it every phase is device-wide: write-through stores,
                               device-wide barriers, any block runs any tile) */
 int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_jobs, const void* const* io, int n_io,
-                   void* sync, int max_blocks, int flags, const void* post, fl_stream_t stream);
+                   void* sync, int max_blocks, int flags, const void* post, const void* guard_sync, fl_stream_t stream);
+/* guard_sync: NULL, or the `sync` area of ANOTHER program whose outputs this one consumes (the optimizer program behind the
+ * training program): while that area's abort word is set this launch does nothing either - a void gradient is never applied. */
 
 #ifdef __cplusplus
 }

@@ -81,7 +81,11 @@ __global__ void clip_coef_kernel(const float* sq, float max_norm, float* coef, f
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, const float* __restrict__ lr_dev,
                             const int* __restrict__ step_dev, float b1, float b2, float eps, float wd,
-                            const float* __restrict__ coef_dev, float gscale, int decoupled) {
+                            const float* __restrict__ coef_dev, float gscale, int decoupled, const float* __restrict__ betas_dev) {
+  if (betas_dev) {
+    b1 = betas_dev[0];
+    b2 = betas_dev[1];
+  }
   const float lr = lr_dev[0];
   const float step = (float)step_dev[0];
   const float bc1 = 1.f - powf(b1, step);
@@ -320,11 +324,11 @@ int fl_clip_coef(const float* sqnorm, float max_norm, float* coef, float* norm_o
 }
 // decoupled=1: AdamW (v2:1026, v2:1247); 0: Adam with L2 (v2:1028). step_dev holds the 1-based step count.
 int fl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, const int32_t* step_dev,
-                 float b1, float b2, float eps, float wd, const float* coef_dev, float gscale, int decoupled,
+                 float b1, float b2, float eps, float wd, const float* coef_dev, float gscale, int decoupled, const float* betas_dev,
                  fl_stream_t stream) {
   FL_REQUIRE(p && g && m && v && lr_dev && step_dev, "fl_adam_step: null arg");
   if (!n) return FL_OK;
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), p, g, m, v, (long long)n, lr_dev, step_dev, b1, b2, eps, wd, coef_dev, gscale, decoupled);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, ST(stream), p, g, m, v, (long long)n, lr_dev, step_dev, b1, b2, eps, wd, coef_dev, gscale, decoupled, betas_dev);
   return fl::check_launch("adam_step");
 }
 

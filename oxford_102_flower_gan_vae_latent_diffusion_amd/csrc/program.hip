@@ -1322,7 +1322,12 @@ __device__ __forceinline__ void adam_tile(const fl_pjob& jb, int t, const ProgIO
   }
   const float lr = ld1g(rp(jb.W[1], io));
   const float step = (float)(*(const __attribute__((address_space(1))) int*)rp(jb.W[2], io) + 1);
-  const float b1 = jb.bias_scale[0], b2 = jb.bias_scale[1], eps = jb.eps, wd = jb.eps2;
+  float b1 = jb.bias_scale[0], b2 = jb.bias_scale[1];
+  if (jb.bias[0]) {  // (beta1, beta2) in device memory: a scheduler changes them between replays of one captured graph
+    b1 = ld1g(rp(jb.bias[0], io));
+    b2 = ld1g(rp(jb.bias[0], io) + 1);
+  }
+  const float eps = jb.eps, wd = jb.eps2;
   const float bc1 = 1.f - powf(b1, step);
   const float bc2s = sqrtf(1.f - powf(b2, step));
   const float cs = gs * coef;
@@ -1630,7 +1635,8 @@ __device__ __forceinline__ int run_tile(const jobwords_t jw, int rt, int k, cons
 // 512 threads: waves 4-7 are the LDS-DMA loaders of the GEMM tiles; the other tile kinds run on waves 0-3 (the loaders
 // shadow them where a tile meets at workgroup barriers, and skip the rest).
 __global__ __launch_bounds__(512, 1) void program_kernel(const fl_pphase* __restrict__ phases, const fl_pjob* __restrict__ jobs,
-                                                         int nphases, int njobs, const ProgIO io, unsigned* sync, int allow_local) {
+                                                         int nphases, int njobs, const ProgIO io, unsigned* sync, int allow_local,
+                                                         const unsigned* guard) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_ok, s_slot;
   __shared__ unsigned s_epoch;
@@ -1672,6 +1678,8 @@ __global__ __launch_bounds__(512, 1) void program_kernel(const fl_pphase* __rest
   // (its barriers would fall through on the stale counters and the phases would compute garbage) until the host has
   // seen the word, re-armed the counters and raised (Program.check / Program.run)
   if (__hip_atomic_load(&sync[ABORT_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  // ... and a program whose INPUT comes from a run that was voided (the optimizer behind the training program) must not apply it
+  if (guard && __hip_atomic_load(const_cast<unsigned*>(&guard[ABORT_WORD]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   bool alive = true;
   if (allow_local) {
     // which XCD am I on, and which of its blocks: the XCD is read from the hardware, the slot is the order of registration.
@@ -2007,7 +2015,7 @@ int fl_program_pack_weight(const float* w, float* out, int N, int K, int ldw, fl
 int fl_program_sync_bytes(void) { return SYNC_UINTS * 4; }
 
 int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_jobs, const void* const* io, int n_io,
-                   void* sync, int max_blocks, int flags, const void* post, fl_stream_t stream) {
+                   void* sync, int max_blocks, int flags, const void* post, const void* guard_sync, fl_stream_t stream) {
   FL_REQUIRE(phases && jobs && sync && n_phases >= 1 && n_jobs >= 1 && n_io >= 0 && n_io <= FL_PROG_MAX_IO && (n_io == 0 || io),
              "fl_program_run: bad args (n_phases=%d n_jobs=%d n_io=%d)", n_phases, n_jobs, n_io);
   FL_REQUIRE((size_t)n_phases * sizeof(fl_pphase) + (size_t)n_jobs * (sizeof(fl_pjob) + 16) <= (size_t)PROG_LDS_BYTES,
@@ -2038,7 +2046,7 @@ int fl_program_run(const void* phases, const void* jobs, int n_phases, int n_job
   const int allow_local = (flags & FL_PROG_XCD_LOCAL) != 0 && G == cus && G % NCTR == 0 && nx <= 32 && (nx & (nx - 1)) == 0;
   hipLaunchKernelGGL(program_kernel, dim3(G), dim3(512), LDS_BYTES, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const fl_pphase*>(phases), reinterpret_cast<const fl_pjob*>(jobs), n_phases, n_jobs, pio,
-                     reinterpret_cast<unsigned*>(sync), allow_local);
+                     reinterpret_cast<unsigned*>(sync), allow_local, reinterpret_cast<const unsigned*>(guard_sync));
   return fl::check_launch("program_kernel");
 }
 

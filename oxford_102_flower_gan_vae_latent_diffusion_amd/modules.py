@@ -481,14 +481,23 @@ class ConditionalUNet(nn.Module):
         from .program import FoldedUNetProgram, UNetProgram
         B = x.shape[0]
         shared_t = t.numel() == 1 and B != 1
-        if FOLDED_FORWARD and not self.training and c is not None and not shared_t and block_masks is None:
-            # frozen-weight inference: linear chains folded, 12 phases instead of 26 (rebuilt when any weight changes); the
-            # per-timestep table covers t < self.max_timesteps (default 1000, v2:564): a larger t voids the run loudly
+        folded = FOLDED_FORWARD and not self.training and c is not None and not shared_t and block_masks is None
+        if folded and not torch.cuda.is_current_stream_capturing():
+            # the folded program tabulates swish(lin1(sinusoid(t))) for t < max_timesteps (set by ConditionalDenoiseDiffusion to its
+            # n_steps; default 1000, v2:564) and swish(lin1(embedding(c))) per class; the reference computes a sinusoid for ANY t
+            # (v2:401-418): a timestep outside the table takes the unfolded program (in-kernel sinusoid, no table). One small
+            # device->host read per eager call; a forward captured in a hipGraph keeps the table's contract (t < max_timesteps,
+            # checked in the kernel: an index outside voids the run and Program.check raises).
+            tmin, tmax = int(t.min()), int(t.max())
+            folded = 0 <= tmin and tmax < getattr(self, "max_timesteps", 1000)
+        if folded:
+            # frozen-weight inference: linear chains folded, 12 phases instead of 26 (rebuilt when any weight changes)
             cache = self.__dict__.setdefault("_folded", {})
             fp = cache.get((B, x.device))
-            if fp is None or fp.key != FoldedUNetProgram.version_key(self):
+            n_tab = getattr(self, "max_timesteps", 1000)
+            if fp is None or fp.key != FoldedUNetProgram.version_key(self) or fp.n_steps != n_tab:
                 cache.clear()
-                fp = cache[(B, x.device)] = FoldedUNetProgram(self, B, x.device, n_steps=getattr(self, "max_timesteps", 1000))
+                fp = cache[(B, x.device)] = FoldedUNetProgram(self, B, x.device, n_steps=n_tab)
             self._pcalls = getattr(self, "_pcalls", 0) + 1
             if self._pcalls % 256 == 0 and not torch.cuda.is_current_stream_capturing():
                 fp.prog.check()
@@ -527,6 +536,9 @@ class ConditionalDenoiseDiffusion:
     def __init__(self, eps_model, n_steps=1000, device=None):
         self.eps_model = eps_model
         self.device = device
+        # the denoiser's folded inference program tabulates its timestep MLP over the timesteps this process can produce
+        if isinstance(eps_model, ConditionalUNet):
+            eps_model.max_timesteps = max(int(getattr(eps_model, "max_timesteps", 0)), int(n_steps))
         # schedule constants are computed on the host exactly like the reference's CPU path (v2:569-571)
         beta = torch.linspace(0.0001, 0.02, n_steps)
         alpha = 1 - beta

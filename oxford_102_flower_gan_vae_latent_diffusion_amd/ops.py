@@ -767,10 +767,11 @@ def clip_coef(sq, max_norm, coef, norm_out=None):
 
 
 def adam_step(p, g, m, v, lr_dev, step_dev, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, coef_dev=None, gscale=1.0,
-              decoupled=True):
-    _chk(p, g, m, v, lr_dev, step_dev, coef_dev)
+              decoupled=True, betas_dev=None):
+    """betas_dev: device tensor (beta1, beta2) that overrides b1, b2 (read at run time: graph replays follow a scheduler)."""
+    _chk(p, g, m, v, lr_dev, step_dev, coef_dev, betas_dev)
     _lib.call("fl_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), _p(step_dev), float(b1), float(b2),
-              float(eps), float(wd), _p(coef_dev), float(gscale), int(decoupled), _stream())
+              float(eps), float(wd), _p(coef_dev), float(gscale), int(decoupled), _p(betas_dev), _stream())
 
 
 def kl_fwd(mu, logvar, want_musq=False):

@@ -209,8 +209,11 @@ class ProgramBuilder:
         self._add(j, [g], [partials])
 
     def adam(self, n, p, g, m, v, partials, lr, step, b1, b2, eps, wd, decoupled, gscale=1.0, max_norm=None, coef=None,
-             gnorm=None):
+             gnorm=None, betas_dev=None):
+        """betas_dev: device tensor (beta1, beta2) read at run time instead of b1, b2."""
         j = np.zeros((), JOB_DTYPE)
+        j["bias"][0] = _ptr(betas_dev)
+        self._hold(betas_dev)
         j["kind"], j["M"], j["N"] = ADAM, 1, 1
         j["K"][0], j["A"][0], j["C"], j["aux"][0], j["aux"][1] = n, _ptr(g), _ptr(p), _ptr(m), _ptr(v)
         j["W"][0], j["W"][1], j["W"][2], j["aux"][2], j["aux"][3] = _ptr(partials), _ptr(lr), _ptr(step), _ptr(coef), _ptr(gnorm)
@@ -328,6 +331,7 @@ class Program:
         self.local_ok = False  # the row-local jobs all work on the same batch rows: phases flagged PHASE_LOCAL may run XCD-local
         self.local = False     # ask for FL_PROG_XCD_LOCAL (set by the builder when local_ok; FL_PROG_LOCAL=0 turns it off)
         self.n_local_phases = 0
+        self.guard = None      # another Program whose outputs this one consumes: while THAT one's run is void, this one does nothing
 
     def run(self, io, post=None):
         """io: list of tensors bound to the IO slots. Enqueues one kernel on the current stream (graph-capturable).
@@ -349,9 +353,11 @@ class Program:
         capturing = torch.cuda.is_current_stream_capturing()
         if not capturing and self._abort_host is not None and int(self._abort_host[0]) != 0:
             self.check()  # an earlier run timed out (seen through the pinned mirror, no sync): re-arm and raise
+        if not capturing and self.guard is not None and self.guard._abort_host is not None and int(self.guard._abort_host[0]) != 0:
+            self.guard.check()  # the producer's run was void: raise instead of consuming it
         lib.call("fl_program_run", ctypes.c_void_p(self.phases.data_ptr()), ctypes.c_void_p(self.jobs.data_ptr()),
                  self.n_phases, self.n_jobs, arr, len(io), ctypes.c_void_p(self.sync.data_ptr()), self.max_blocks,
-                 1 if self.local else 0, pbuf, ops._stream())
+                 1 if self.local else 0, pbuf, ctypes.c_void_p(self.guard.sync.data_ptr() if self.guard is not None else 0), ops._stream())
         if not capturing and self._abort_host is not None:  # cheap health check: async mirror of the abort word, read next call
             self._abort_host.copy_(self.sync[SYNC_ABORT_WORD:SYNC_ABORT_WORD + 1], non_blocking=True)
 

@@ -242,12 +242,13 @@ class OptimizerProgram:
         dev = fp.flat.device
         self.opt, self.n, self.gscale = opt, n, gscale
         self.partials = torch.zeros(256, dtype=torch.float32, device=dev)
-        self.key = (n, gscale, tuple(opt.betas), opt.eps, opt.wd, opt.decoupled, opt.max_norm, fp.flat.data_ptr(), fp.grad.data_ptr())
+        self.key = (n, gscale, opt.eps, opt.wd, opt.decoupled, opt.max_norm, fp.flat.data_ptr(), fp.grad.data_ptr())
         pb = ProgramBuilder()
         pb.sqnorm(n, fp.grad, self.partials)
         pb.barrier()
         pb.adam(n, fp.flat, fp.grad, opt.m, opt.v, self.partials, opt.lr, opt.step_count, opt.betas[0], opt.betas[1], opt.eps,
-                opt.wd, opt.decoupled, gscale=gscale, max_norm=opt.max_norm, coef=opt.coef, gnorm=opt.grad_norm)
+                opt.wd, opt.decoupled, gscale=gscale, max_norm=opt.max_norm, coef=opt.coef, gnorm=opt.grad_norm,
+                betas_dev=opt.betas_dev)
         self.prog = pb.finalize(dev)
 
     def run(self):

@@ -87,6 +87,9 @@ class FusedAdam:
         self.m = torch.zeros_like(fp.flat)
         self.v = torch.zeros_like(fp.flat)
         self.lr = torch.tensor([lr], dtype=torch.float32, device=dev)
+        # (beta1, beta2) live on the device like lr: torch's OneCycleLR cycles beta1 every batch (v2:1031-1037), and a captured
+        # step or a resident optimizer program must follow it without being rebuilt
+        self.betas_dev = torch.tensor([betas[0], betas[1]], dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.coef = torch.ones(1, dtype=torch.float32, device=dev)
@@ -96,9 +99,10 @@ class FusedAdam:
         self.lr.fill_(lr)
 
     def set_beta1(self, b1):
-        """torch's OneCycleLR cycles AdamW's beta1 (schedules.OneCycle). A host scalar: takes effect in eager steps and in
-        graphs captured afterwards."""
+        """torch's OneCycleLR cycles AdamW's beta1 (schedules.OneCycle). Device-resident like lr: eager steps, captured
+        graphs and the resident optimizer program all read it at run time."""
         self.betas = (float(b1), self.betas[1])
+        self.betas_dev[0:1].fill_(float(b1))
 
     def state_dict(self):
         return {"m": self.m.detach().cpu(), "v": self.v.detach().cpu(), "step": self.step_count.detach().cpu(),
@@ -111,6 +115,7 @@ class FusedAdam:
         self.lr.copy_(st["lr"])
         if "betas" in st:
             self.betas = tuple(st["betas"])
+            self.betas_dev.copy_(torch.tensor(self.betas, dtype=torch.float32))
 
     def step(self, gscale=1.0, n=None):
         fp = self.fp
@@ -126,7 +131,7 @@ class FusedAdam:
             coef = self.coef
         ops.step_counter_add(self.step_count, None, 1)
         ops.adam_step(fp.flat[:n], g, self.m[:n], self.v[:n], self.lr, self.step_count, self.betas[0], self.betas[1],
-                      self.eps, self.wd, coef, gscale, self.decoupled)
+                      self.eps, self.wd, coef, gscale, self.decoupled, betas_dev=self.betas_dev)
         fp.bump()
 
 
@@ -203,6 +208,7 @@ class DDPMTrainer:
         xt = ops.q_sample(z, eps, t, d.alpha_bar)
         if use_prog:
             prog = self._train_program(B, block_masks is not None)
+            self._last_tp = prog.programs[-1]   # the optimizer program watches this run's abort word
             post = [(r.state(z.device), n) for r, n in ((d.rng, d_adv), (self.unet.rng, m_adv)) if n]
             self.eps_theta = prog.run(xt, t, labels, eps, block_masks, head_masks, post=post)   # loss and every gradient included
             return
@@ -239,9 +245,12 @@ class DDPMTrainer:
         if self.persistent:
             from .program_train import OptimizerProgram
             o, n, gs = self.opt, self.fp.n_active, 1.0 / self.world
-            key = (n, gs, tuple(o.betas), o.eps, o.wd, o.decoupled, o.max_norm, self.fp.flat.data_ptr(), self.fp.grad.data_ptr())
+            key = (n, gs, o.eps, o.wd, o.decoupled, o.max_norm, self.fp.flat.data_ptr(), self.fp.grad.data_ptr())
             if self._oprog is None or self._oprog.key != key:
                 self._oprog = OptimizerProgram(o, n, gs)
+            # the optimizer must not apply a gradient whose forward / backward run was void (barrier time-out, label outside
+            # the table): it watches the training program's abort word
+            self._oprog.prog.guard = getattr(self, "_last_tp", None)
             self._oprog.run()
             return
         self.opt.step(gscale=1.0 / self.world)
@@ -343,6 +352,60 @@ class DDPMTrainer:
         self.gO.replay()
         self._replayed()
         return self.loss
+
+    def measure_comm(self, batches, labels, steps_n=10, overlapped=True):
+        """Timing of the data-parallel collective (N > 1; run AFTER a timed region, it synchronises): `allreduce_ms` = the
+        flat-gradient all-reduce alone (HIP events around `steps_n` back-to-back collectives, median), `allreduce_exposed_ms` =
+        what a step waits for it (overlapped schedule: from the end of the next batch's encoder graph to the collective's
+        completion on the compute stream; plain schedule: its whole duration), plus the step pieces it hides under."""
+        import statistics
+        dev = self.dev
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        n = self.fp.n_active
+        alone = []
+        for _ in range(steps_n):
+            e0, e1 = ev(), ev()
+            torch.cuda.synchronize(dev)
+            e0.record()
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(self.fp.grad[:n], group=self.pg)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            alone.append(e0.elapsed_time(e1))
+        res = {"allreduce_ms": statistics.median(alone), "allreduce_bytes": 4 * n, "world": self.world,
+               "schedule": "all-reduce of step k under the encoder of batch k+1" if overlapped else "all-reduce between the two graphs"}
+        if overlapped and hasattr(self, "gE"):
+            exposed, enc, den = [], [], []
+            for i in range(steps_n):
+                e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+                self.z_in.copy_(self.z_next)
+                self.lab_in.copy_(self.lab_next)
+                e0.record()
+                self.gU.replay()
+                e1.record()
+                work = None
+                if self.world > 1:
+                    import torch.distributed as dist
+                    work = dist.all_reduce(self.fp.grad[:n], group=self.pg, async_op=True)
+                self.static_data.copy_(batches[i % len(batches)])
+                self.gE.replay()
+                self.lab_next.copy_(labels[i % len(labels)])
+                e2.record()
+                if work is not None:
+                    work.wait()
+                e3.record()
+                self.gO.replay()
+                self._replayed()
+                torch.cuda.synchronize(dev)
+                den.append(e0.elapsed_time(e1))
+                enc.append(e1.elapsed_time(e2))
+                exposed.append(e2.elapsed_time(e3))
+            res.update({"allreduce_exposed_ms": statistics.median(exposed), "encoder_graph_ms": statistics.median(enc),
+                        "denoiser_program_ms": statistics.median(den)})
+        else:
+            res["allreduce_exposed_ms"] = res["allreduce_ms"]
+        return res
 
     # ---- cross-step software pipeline -------------------------------------------------------------------
     # The frozen encoder of batch k+1 does not depend on the denoiser update of batch k (v2:1257-1259 runs under

@@ -34,6 +34,8 @@ def _inputs(nb=2, B=8):
 
 
 def _worker(rank, world, port, ret, pipelined):
+    import faulthandler
+    faulthandler.enable()   # a crash of a spawned rank (SIGSEGV in native code) leaves a Python stack in the test log
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -53,7 +55,36 @@ def _worker(rank, world, port, ret, pipelined):
     per = batches[0]["data"].shape[0] // world
     sl = slice(rank * per, (rank + 1) * per)
     res = {}
-    if not pipelined:
+    if pipelined == "overlapped":
+        # the N > 1 schedule of bench.py (capture_overlapped / prime_overlapped / replay_overlapped: all-reduce of step k
+        # issued async while the encoder graph of batch k+1 replays, work.wait(), optimizer graph) against plain step() on
+        # the same draws: same seeds per rank for both runs, weights / optimizer / RNG state restored in between
+        def reseed():
+            for r, s_ in ((ae.rng, 100 + rank), (un.rng, 300 + rank), (tr.diffusion.rng, 200 + rank)):
+                r.manual_seed(s_)
+        un.train()
+        n = 3
+        data = [batches[i % 2]["data"][sl].to(dev) for i in range(n + 1)]
+        labs = [batches[i % 2]["labels"][sl].to(dev) for i in range(n + 1)]
+        sd0 = {k: v.clone() for k, v in un.state_dict().items()}
+        reseed()
+        res["plain_loss"] = [float(tr.step(data[i], labs[i])) for i in range(n)]
+        res["plain_flat"] = tr.fp.flat.detach().cpu().clone()
+        un.load_state_dict(sd0)
+        tr.opt.m.zero_(); tr.opt.v.zero_(); tr.opt.step_count.zero_()
+        tr.capture_overlapped(data[0].clone(), labs[0].clone())
+        un.load_state_dict(sd0)                  # capture ran warm-up steps
+        tr.opt.m.zero_(); tr.opt.v.zero_(); tr.opt.step_count.zero_()
+        reseed()
+        tr.prime_overlapped(data[0], labs[0])
+        res["over_loss"] = []
+        for i in range(n):
+            l = tr.replay_overlapped(data[i + 1], labs[i + 1])
+            torch.cuda.synchronize()
+            res["over_loss"].append(float(l))
+        res["over_flat"] = tr.fp.flat.detach().cpu().clone()
+        res["comm"] = tr.measure_comm(data, labs, steps_n=2, overlapped=True)
+    elif not pipelined:
         for i, b in enumerate(batches):
             tr.step(b["data"][sl].to(dev), b["labels"][sl].to(dev), b["re"][sl].to(dev), b["t"][sl].to(dev), b["eps"][sl].to(dev))
             res["gn%d" % i] = float(tr.opt.grad_norm)
@@ -118,3 +149,21 @@ def test_dp_ddpm_pipelined_graphs_keep_ranks_identical(dev):
     assert ret[0]["loss"] != ret[1]["loss"]  # per-rank noise
     for k in KEYS:
         assert torch.equal(ret[0]["params"][k], ret[1]["params"][k]), "ranks diverged: " + k
+
+
+def test_dp_ddpm_overlapped_schedule_two_ranks(dev):
+    """bench.py's N > 1 schedule with world_size 2 (gloo, both ranks on cuda:0, multi-kernel denoiser: two persistent programs
+    cannot share one GPU): the z / label double buffers, the async all-reduce under the next batch's encoder graph and the
+    work.wait() ordering reproduce plain step() on the same draws bit for bit, on both ranks, and the replicated weights of the
+    two ranks are identical although each rank drew its own noise."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret, "overlapped"), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert ret[r]["over_loss"] == ret[r]["plain_loss"], "rank %d: %s vs %s" % (r, ret[r]["over_loss"], ret[r]["plain_loss"])
+        assert torch.equal(ret[r]["over_flat"], ret[r]["plain_flat"]), "rank %d: overlapped schedule != plain steps" % r
+        c = ret[r]["comm"]
+        assert c["world"] == 2 and c["allreduce_ms"] > 0 and c["allreduce_exposed_ms"] >= 0 and c["allreduce_bytes"] > 4e7
+    assert torch.equal(ret[0]["over_flat"], ret[1]["over_flat"]), "ranks diverged"
+    assert ret[0]["over_loss"] != ret[1]["over_loss"]   # per-rank noise

@@ -220,6 +220,69 @@ def test_folded_unet_program(dev, B):
     fp2.prog.check()
 
 
+def test_eval_forward_accepts_any_timestep(dev):
+    """v2:401-418 computes a sinusoid for ANY t: the eval forward leaves the folded program (per-timestep table) for the
+    unfolded one when a timestep lies outside the table instead of voiding the run; ConditionalDenoiseDiffusion(n_steps=N)
+    widens the table to its N."""
+    un = _unet(dev, 3).eval()
+    B = 16
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 256, generator=g).to(dev)
+    c = torch.randint(0, 102, (B,), generator=g).to(dev)
+    t_out = torch.tensor([0, 999, 1000, 5000] * 4, device=dev)
+    t_in = torch.randint(0, 1000, (B,), generator=g).to(dev)
+    with torch.no_grad():
+        for t in (t_out, t_in, t_out):
+            out = un(x, t, c)
+            ref, _ = engine.unet_forward(un, x, t, c)
+            close(out, ref, 3e-5, "eval forward, t max %d" % int(t.max()))
+        for fp in un._folded.values():
+            fp.prog.check()   # no run was voided on the way
+        M.ConditionalDenoiseDiffusion(un, n_steps=2000, device=dev)
+        assert un.max_timesteps == 2000
+        t_wide = torch.full((B,), 1500, device=dev)
+        out = un(x, t_wide, c)
+        assert any(fp.n_steps == 2000 for fp in un._folded.values())   # the folded program again, with a wider table
+        close(out, engine.unet_forward(un, x, t_wide, c)[0], 3e-5, "t = 1500 inside a 2000-step table")
+
+
+def test_weight_pack_image_and_packed_gemm(dev):
+    """fl_program_pack_weight lays a [N][K] weight out as the LDS-DMA tile reads it (32-column tile, 128-k chunk, XOR-swizzled
+    16-byte blocks); a frozen-weights GEMM on the packed copies (three concatenated-K segments, one a view with an offset
+    and a wider pitch) equals the same GEMM on the row-major weights."""
+    import numpy as np
+    N, K, ldw = 64, 256, 320
+    w = rnd(N, ldw, seed=3)
+    img = ops.program_pack_weight(w.to(dev), N, K, ldw).cpu().numpy().reshape(N // 32, K // 128, 32, 32, 4)
+    wn = w.numpy()
+    for ct in range(N // 32):
+        for ch in range(K // 128):
+            for r in (0, 1, 15, 16, 31):
+                for pb in (0, 5, 31):
+                    j = pb ^ (r & 15)
+                    assert np.array_equal(img[ct, ch, r, pb], wn[32 * ct + r, 128 * ch + 4 * j:128 * ch + 4 * j + 4])
+    B, Nn = 96, 128
+    a0, a1, a2 = rnd(B, 256, seed=4), rnd(B, 128, seed=5), rnd(B, 384, seed=6)
+    w0, wcat, w2 = rnd(Nn, 256, seed=7, scale=0.1), rnd(Nn, 512, seed=8, scale=0.1), rnd(Nn, 384, seed=9, scale=0.1)
+    bias = rnd(Nn, seed=10)
+    outs = []
+    for frozen in (False, True):
+        pb = P.ProgramBuilder(frozen_weights=frozen)
+        a0d, a1d, a2d, w0d, wcd, w2d = (v.to(dev) for v in (a0, a1, a2, w0, wcat, w2))
+        o = torch.empty(B, Nn, device=dev)
+        pb.gemm(B, Nn, [(a0d, 256, 256, w0d, 256), (a1d, 128, 128, (wcd, 384), 512), (a2d, 384, 384, w2d, 384)], o, Nn,
+                [(bias.to(dev), 1.0)])
+        prog = pb.finalize(dev)
+        flags = np.frombuffer(prog.jobs.cpu().numpy().tobytes(), dtype=P.JOB_DTYPE)["flags"][0]
+        assert bool(flags & P.PG_WPACK) == frozen and flags & P.PG_DMA
+        prog.run([])
+        prog.check()
+        outs.append(o)
+    ref = a0.double() @ w0.double().t() + a1.double() @ wcat[:, 384:].double().t() + a2.double() @ w2.double().t() + bias.double()
+    close(outs[0], ref, 2e-5, "row-major weights")
+    assert torch.equal(outs[0], outs[1]), "packed weights: same products in the same order"
+
+
 def test_unet_program_ce_given(dev):
     """Sampler form: one shared timestep, class path hoisted out of the loop (ce computed once)."""
     un = _unet(dev, 3).eval()

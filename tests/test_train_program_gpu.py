@@ -342,3 +342,93 @@ def test_overlapped_dp_schedule_equals_plain_steps(dev):
         lb.append(float(l))
     assert lb == la
     assert torch.equal(tr.fp.flat, pa)
+
+
+def test_beta1_schedule_reaches_captured_and_resident_optimizers(dev):
+    """torch's OneCycleLR cycles AdamW's beta1 every batch (v2:1031-1037). beta1 lives on the device like lr: a captured
+    multi-kernel step and the resident optimizer program both follow set_beta1 without being rebuilt, and equal eager steps with
+    the same schedule (it used to be baked into graphs and to rebuild the optimizer program on every change)."""
+    n = 4096 * 3
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) for _ in range(4)]
+    b1s = [0.95, 0.9, 0.85, 0.93]
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(p0.clone())
+
+    def run(mode):
+        m = Holder().to(dev)
+        fp = steps.FlatParams(m)
+        opt = steps.FusedAdam(fp, lr=1e-2, betas=(0.95, 0.999), weight_decay=1e-2, decoupled=True, max_norm=1.0)
+        gbuf = fp.grad
+        if mode == "graph":
+            gbuf.copy_(grads[0].to(dev))
+            opt.step()                       # warm-up (sizes workspaces), then restore
+            fp.flat.copy_(p0.to(dev)); opt.m.zero_(); opt.v.zero_(); opt.step_count.zero_()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                opt.step()
+        elif mode == "program":
+            from oxford_102_flower_gan_vae_latent_diffusion_amd.program_train import OptimizerProgram
+            op = OptimizerProgram(opt, fp.n_active)
+        for gi, b1 in zip(grads, b1s):
+            opt.set_beta1(b1)
+            gbuf.copy_(gi.to(dev))
+            if mode == "eager":
+                opt.step()
+            elif mode == "graph":
+                gr.replay()
+            else:
+                op.run()
+        torch.cuda.synchronize()
+        if mode == "program":
+            op.prog.check()
+        return fp.flat.detach().cpu().clone()
+
+    eager = run("eager")
+    # torch reference with the same per-step beta1
+    pt = torch.nn.Parameter(p0.clone().double())
+    o = torch.optim.AdamW([pt], lr=1e-2, betas=(0.95, 0.999), weight_decay=1e-2)
+    for gi, b1 in zip(grads, b1s):
+        o.param_groups[0]["betas"] = (b1, 0.999)
+        pt.grad = gi.double().clone()
+        torch.nn.utils.clip_grad_norm_([pt], 1.0)
+        o.step()
+    close(eager, pt.detach(), 2e-6, "eager steps vs torch AdamW with a cycled beta1")
+    assert torch.equal(run("graph"), eager), "a captured step ignores set_beta1"
+    close(run("program"), eager, 1e-6, "optimizer program vs eager steps with a cycled beta1")
+
+
+def test_optimizer_program_does_not_apply_a_void_gradient(dev):
+    """The optimizer program watches the training program's abort word: after a voided forward / backward run (a label outside the
+    embedding table) it does nothing - weights, moments and the step count stay put - until the host has seen and cleared it."""
+    B = 32
+    ae = _seeded(M.SimpleAutoencoder(), 42).to(dev).eval()
+    un = _seeded(M.ConditionalUNet(), 44).to(dev).train()
+    tr = steps.DDPMTrainer(ae, un, lr=1e-3, persistent=True)
+    g = torch.Generator().manual_seed(1)
+    data = (torch.rand(B, 3, 64, 64, generator=g) * 2 - 1).to(dev)
+    labels = torch.randint(0, 102, (B,), generator=g).to(dev)
+    tr.step(data, labels)
+    torch.cuda.synchronize()
+    tr.check_programs()
+    before, steps_before = tr.fp.flat.clone(), int(tr.opt.step_count)
+    bad = labels.clone()
+    bad[3] = 102                                   # outside the 102-row class table: the training program voids its run
+    z = tr.encode(data)
+    tr.fwd_bwd(z, bad)
+    torch.cuda.synchronize()
+    tr._oprog.prog._abort_host.zero_()              # (keep the eager host-side shortcut out of the way: the DEVICE-side guard is under test)
+    tr._tprog[(B, True)].prog._abort_host.zero_()
+    tr._oprog.run()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.fp.flat, before) and int(tr.opt.step_count) == steps_before
+    with pytest.raises(RuntimeError, match="outside its table"):
+        tr.check_programs()
+    tr.step(data, labels)                           # cleared: training goes on
+    torch.cuda.synchronize()
+    tr.check_programs()
+    assert int(tr.opt.step_count) == steps_before + 1 and not torch.equal(tr.fp.flat, before)

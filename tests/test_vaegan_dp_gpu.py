@@ -33,6 +33,8 @@ def _inputs():
 
 
 def _worker(rank, world, port, ret, lambda_gan):
+    import faulthandler
+    faulthandler.enable()   # a crash of a spawned rank leaves a Python stack in the test log
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
