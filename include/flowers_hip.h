@@ -93,7 +93,12 @@ int fl_gemm_f32(const float* A, int64_t lda, int a_layout,
  * shape as y).  x:(B,H,W,Cin) wp:[Cout][kh][kw][Cin]  y:(B,Ho,Wo,Cout) or, when
  * out_nchw != 0, (B,Cout,Ho,Wo).  Cin % 4 == 0.
  * Replaces nn.Conv2d forward: v2:162,165 (3x3 s1 p1), v2:186, v2:192,198,204
- * (4x4 s2 p1), v2:273,276, VGG16 convs (v2:965), Discriminator64 (v2:987-1002). */
+ * (4x4 s2 p1), v2:273,276, VGG16 convs (v2:965), Discriminator64 (v2:987-1002).
+ * INPUT RANGE of the RGB stem (3 -> 64 channels, 3x3 s1 p1, Cin padded to 4) in the default "split" GEMM math: that shape runs
+ * on the f16x2 stem kernel (conv_first.hip), which scales the taps by a fixed 2^6 before splitting them into fp16 pieces: it is
+ * exact-to-fp32 for |x| < 1023 (images, normalised or not, are far inside) and returns NaN - loudly, never a wrong number - for
+ * larger inputs. FL_STEM_FP32=1 or fl_set_gemm_math(FL_GEMM_FP32) select the fp32-MFMA stem, which has no range limit.
+ * The same holds for fl_conv2d_fwd_instnorm. Every other shape takes x_amax / x_exp explicitly (fl_conv2d_fwd_f16x2). */
 int fl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y,
                   int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
                   int act, float act_param, const float* R, int out_nchw,
@@ -243,7 +248,15 @@ int fl_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
  * (B,heads,HW,HW): the normalised weights, kept only when a backward will need them. QK^T and PV on v_mfma_f32_32x32x2_f32
  * (exact fp32); the score tile is built transposed so that the row softmax is in-lane arithmetic + one wave shuffle and the
  * accumulator tile feeds the PV MFMA as it stands. Needs HW % 32 == 0, C / heads <= 32. */
-int fl_attention_fwd(const float* qkv, float* out, float* P, int B, int HW, int C, int heads, float scale, fl_stream_t stream);
+int fl_attention_fwd(const float* qkv, float* out, float* P, float* stats, int B, int HW, int C, int heads, float scale,
+                     fl_stream_t stream);
+/* stats optional (B,heads,HW,2): per query the max of scale*s and the sum of exp - all the backward needs to recompute P.
+ * Backward of the same core (v2:446-457) in two launches, no (HW x HW) tensor in HBM, no atomics: a dQ kernel (one wave = 32
+ * queries) and a dK / dV kernel (one wave = 32 keys), both recomputing the probabilities from Q, K and `stats`; merged / dmerged
+ * in the forward's d-major channel order, dqkv in the qkv layout (every element written). Workspace: B*heads*HW floats. */
+size_t fl_attention_bwd_workspace_bytes(int B, int HW, int heads);
+int fl_attention_bwd(const float* qkv, const float* merged, const float* dmerged, const float* stats, float* dqkv, int B, int HW,
+                     int C, int heads, float scale, void* ws, size_t ws_bytes, fl_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Residual-block tail: CALayer (v2:53-67) x SpatialAttention (v2:69-81) x residual+Swish

@@ -19,6 +19,7 @@ struct AttnArgs {
   const float* qkv;
   float* out;
   float* P;
+  float* stats;  // optional (B, heads, HW, 2): row max of scale * s and sum of exp - what the backward recomputes P from
   int B, HW, C, nh, d;
   float scale;
 };
@@ -68,6 +69,11 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnArgs g) {
     m = mn;
   }
   const float inv_l = 1.0f / l;
+  if (g.stats && ks == 0) {
+    float* st = g.stats + (((size_t)b * g.nh + h) * g.HW + q0 + lq) * 2;
+    st[0] = m;
+    st[1] = l;
+  }
 
   // ---- pass 2: P = exp(scale s - m) / l, O^T += V^T P^T
   f32x16 o;
@@ -100,23 +106,196 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnArgs g) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- backward
+// dQ, dK, dV of the attention core in two launches, no (HW x HW) tensor in HBM and no atomics: the probabilities are
+// recomputed from Q, K and the forward's row statistics (m = max of scale*s, l = sum of exp).
+//   dV = P^T dO;  dP = dO V^T;  D_q = sum_k P_qk dP_qk = <dO_q, O_q>;  dS = scale * P o (dP - D);  dQ = dS K;  dK = dS^T Q
+// dmerged / merged use the forward's d-major channel order (channel = i * heads + head), dqkv the qkv layout.
+struct AttnBwdArgs {
+  const float* qkv;
+  const float* dmerged;
+  const float* merged;
+  const float* stats;
+  float* dqkv;
+  float* D;  // (B, heads, HW): written by the dQ kernel, read by the dK / dV kernel
+  int B, HW, C, nh, d;
+  float scale;
+};
+
+// One wave = 32 queries (a lane is a query, as in the forward): S^T and dP^T tiles (keys x queries) per key tile, dS^T in
+// lane, and the accumulator tile is the B operand of dQ^T += K^T dS^T as it stands.
+template <int DH>
+__global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const AttnBwdArgs g) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lq = lane & 31, ks = lane >> 5;
+  const int q0 = (blockIdx.x * 4 + wid) * 32;
+  if (q0 >= g.HW) return;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int C3 = 3 * g.C, d = g.d, nh = g.nh;
+  const float* base = g.qkv + (size_t)b * g.HW * C3 + h * d;
+  const float* Qr = base + (size_t)(q0 + lq) * C3;
+  const float* dOr = g.dmerged + ((size_t)b * g.HW + q0 + lq) * g.C + h;  // dO[q][i] = dOr[i * nh]
+  const float* Or = g.merged + ((size_t)b * g.HW + q0 + lq) * g.C + h;
+  float qf[DH / 2], dof[DH / 2];
+  float Dq = 0.f;
+#pragma unroll
+  for (int j = 0; j < DH / 2; ++j) {
+    const int i = 2 * j + ks;
+    qf[j] = i < d ? Qr[i] : 0.f;
+    dof[j] = i < d ? dOr[(size_t)i * nh] : 0.f;
+    Dq += i < d ? dof[j] * Or[(size_t)i * nh] : 0.f;
+  }
+  Dq += __shfl_xor(Dq, 32, 64);
+  const float* st = g.stats + (((size_t)b * nh + h) * g.HW + q0 + lq) * 2;
+  const float m = st[0], inv_l = 1.0f / st[1];
+  if (ks == 0) g.D[((size_t)b * nh + h) * g.HW + q0 + lq] = Dq;
+  f32x16 o;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) o[e] = 0.f;
+  const float* Kb = base + g.C;
+  const float* Vb = base + 2 * g.C;
+  const int ntile = g.HW / 32;
+  for (int kt = 0; kt < ntile; ++kt) {
+    const float* Kr = Kb + (size_t)(kt * 32 + lq) * C3;
+    const float* Vr = Vb + (size_t)(kt * 32 + lq) * C3;
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < DH / 2; ++j) {
+      const int i = 2 * j + ks;
+      const float kv = i < d ? Kr[i] : 0.f, vv = i < d ? Vr[i] : 0.f;
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qf[j], s, 0, 0, 0);     // S^T[key][q]
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, dof[j], dp, 0, 0, 0);  // dP^T[key][q] = <V_key, dO_q>
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = expf(s[e] * g.scale - m) * inv_l * (dp[e] - Dq) * g.scale;  // dS^T
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * ks;
+      const float kk = lq < d ? Kb[(size_t)key * C3 + lq] : 0.f;  // A operand: lane (row i = lq, k slot ks) = K[key][i]
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, s[e], o, 0, 0, 0);
+    }
+  }
+  float* dQ = g.dqkv + ((size_t)b * g.HW + q0 + lq) * C3 + h * d;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int i = (e & 3) + 8 * (e >> 2) + 4 * ks;
+    if (i < d) dQ[i] = o[e];
+  }
+}
+
+// One wave = 32 keys (a lane is a key): S and dP tiles (queries x keys) per query tile; P and dS tiles are the B operands of
+// dV^T += dO^T P and dK^T += Q^T dS as they stand.
+template <int DH>
+__global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArgs g) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lq = lane & 31, ks = lane >> 5;
+  const int k0 = (blockIdx.x * 4 + wid) * 32;
+  if (k0 >= g.HW) return;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int C3 = 3 * g.C, d = g.d, nh = g.nh;
+  const float* base = g.qkv + (size_t)b * g.HW * C3 + h * d;
+  const float* Kr = base + g.C + (size_t)(k0 + lq) * C3;
+  const float* Vr = base + 2 * g.C + (size_t)(k0 + lq) * C3;
+  float kf[DH / 2], vf[DH / 2];
+#pragma unroll
+  for (int j = 0; j < DH / 2; ++j) {
+    const int i = 2 * j + ks;
+    kf[j] = i < d ? Kr[i] : 0.f;
+    vf[j] = i < d ? Vr[i] : 0.f;
+  }
+  f32x16 dk, dv;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dk[e] = dv[e] = 0.f;
+  const float* dOb = g.dmerged + (size_t)b * g.HW * g.C + h;
+  const float* stb = g.stats + ((size_t)b * nh + h) * g.HW * 2;
+  const float* Db = g.D + ((size_t)b * nh + h) * g.HW;
+  const int ntile = g.HW / 32;
+  for (int qt = 0; qt < ntile; ++qt) {
+    const float* Qr = base + (size_t)(qt * 32 + lq) * C3;          // A operand rows: this lane's query of the tile
+    const float* dOr = dOb + (size_t)(qt * 32 + lq) * g.C;
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < DH / 2; ++j) {
+      const int i = 2 * j + ks;
+      const float qv = i < d ? Qr[i] : 0.f, gv = i < d ? dOr[(size_t)i * nh] : 0.f;
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, kf[j], s, 0, 0, 0);    // S[q][key]
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, vf[j], dp, 0, 0, 0);  // dP[q][key]
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int q = qt * 32 + (e & 3) + 8 * (e >> 2) + 4 * ks;  // the query row register e of this lane half holds
+      const float p = expf(s[e] * g.scale - stb[2 * q]) / stb[2 * q + 1];
+      dp[e] = p * (dp[e] - Db[q]) * g.scale;  // dS[q][key]
+      s[e] = p;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int q = qt * 32 + (e & 3) + 8 * (e >> 2) + 4 * ks;
+      const float gq = lq < d ? dOb[(size_t)q * g.C + (size_t)lq * nh] : 0.f;  // A operand: lane (row i = lq, k slot ks) = dO[q][i]
+      const float qq = lq < d ? base[(size_t)q * C3 + lq] : 0.f;               //                                        = Q[q][i]
+      dv = __builtin_amdgcn_mfma_f32_32x32x2f32(gq, s[e], dv, 0, 0, 0);
+      dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qq, dp[e], dk, 0, 0, 0);
+    }
+  }
+  float* dK = g.dqkv + ((size_t)b * g.HW + k0 + lq) * C3 + g.C + h * d;
+  float* dV = dK + g.C;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int i = (e & 3) + 8 * (e >> 2) + 4 * ks;
+    if (i < d) {
+      dK[i] = dk[e];
+      dV[i] = dv[e];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
-int fl_attention_fwd(const float* qkv, float* out, float* P, int B, int HW, int C, int heads, float scale, fl_stream_t stream) {
+int fl_attention_fwd(const float* qkv, float* out, float* P, float* stats, int B, int HW, int C, int heads, float scale,
+                     fl_stream_t stream) {
   FL_REQUIRE(qkv && out && B >= 0 && HW > 0 && C > 0 && heads > 0, "fl_attention_fwd: bad arguments");
   FL_REQUIRE(C % heads == 0 && HW % 32 == 0, "fl_attention_fwd: C %% heads == 0 and HW %% 32 == 0 required (C=%d heads=%d HW=%d)", C, heads, HW);
   const int d = C / heads;
   FL_REQUIRE(d <= 32, "fl_attention_fwd: head dim %d > 32", d);
   if (B == 0) return FL_OK;
   AttnArgs g;
-  g.qkv = qkv; g.out = out; g.P = P; g.B = B; g.HW = HW; g.C = C; g.nh = heads; g.d = d; g.scale = scale;
+  g.qkv = qkv; g.out = out; g.P = P; g.stats = stats; g.B = B; g.HW = HW; g.C = C; g.nh = heads; g.d = d; g.scale = scale;
   dim3 grid((unsigned)fl::cdiv(HW, 128), (unsigned)heads, (unsigned)B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (d <= 16) hipLaunchKernelGGL(attention_fwd_kernel<16>, grid, dim3(256), 0, s, g);
   else hipLaunchKernelGGL(attention_fwd_kernel<32>, grid, dim3(256), 0, s, g);
   return fl::check_launch("attention_fwd_kernel");
+}
+
+size_t fl_attention_bwd_workspace_bytes(int B, int HW, int heads) { return (size_t)B * heads * HW * sizeof(float); }
+
+int fl_attention_bwd(const float* qkv, const float* merged, const float* dmerged, const float* stats, float* dqkv, int B, int HW,
+                     int C, int heads, float scale, void* ws, size_t ws_bytes, fl_stream_t stream) {
+  FL_REQUIRE(qkv && merged && dmerged && stats && dqkv && B >= 0 && HW > 0 && C > 0 && heads > 0, "fl_attention_bwd: bad arguments");
+  FL_REQUIRE(C % heads == 0 && HW % 32 == 0 && C / heads <= 32, "fl_attention_bwd: C %% heads == 0, HW %% 32 == 0, C / heads <= 32 (C=%d heads=%d HW=%d)",
+             C, heads, HW);
+  if (B == 0) return FL_OK;
+  FL_REQUIRE(ws && ws_bytes >= fl_attention_bwd_workspace_bytes(B, HW, heads), "fl_attention_bwd: workspace too small");
+  AttnBwdArgs g;
+  g.qkv = qkv; g.dmerged = dmerged; g.merged = merged; g.stats = stats; g.dqkv = dqkv; g.D = reinterpret_cast<float*>(ws);
+  g.B = B; g.HW = HW; g.C = C; g.nh = heads; g.d = C / heads; g.scale = scale;
+  dim3 grid((unsigned)fl::cdiv(HW, 128), (unsigned)heads, (unsigned)B);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (g.d <= 16) {
+    hipLaunchKernelGGL(attention_bwd_dq_kernel<16>, grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel<16>, grid, dim3(256), 0, s, g);
+  } else {
+    hipLaunchKernelGGL(attention_bwd_dq_kernel<32>, grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel<32>, grid, dim3(256), 0, s, g);
+  }
+  return fl::check_launch("attention_bwd_kernels");
 }
 
 }  // extern "C"

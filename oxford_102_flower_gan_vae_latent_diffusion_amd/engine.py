@@ -79,9 +79,21 @@ class PackCache:
 
     def ln_bound(self, ln, n, prev=None):
         """(1,) device float bounding |ln(.)| (and what Swish / (0,1) gates make of it) for a norm over n elements, plus
-        the bound `prev` of a residual input: the range information of the f16x2 convs. Per weight version."""
-        return self.get(("lnbound", id(ln), n, id(prev)), [ln.weight, ln.bias],
-                        lambda: ops.affine_bound(ln.weight.detach(), ln.bias.detach(), float(n) ** 0.5, prev))
+        the bound of a residual input given as prev = (its norm module, its n): the range information of the f16x2 convs.
+        Keyed by the producing MODULES and versioned by every weight of the chain (keying on id() of the cached
+        `prev` tensor grew the cache by one entry per weight version and could hit a stale entry through a recycled id)."""
+        params = [ln.weight, ln.bias]
+        key = ("lnbound", id(ln), n)
+        if prev is not None:
+            pln, pn = prev
+            params += [pln.weight, pln.bias]
+            key += (id(pln), pn)
+
+        def make():
+            pb = self.ln_bound(prev[0], prev[1]) if prev is not None else None
+            return ops.affine_bound(ln.weight.detach(), ln.bias.detach(), float(n) ** 0.5, pb)
+
+        return self.get(key, params, make)
 
 
 def _d(p):
@@ -179,7 +191,7 @@ def encoder_infer(enc, x, want_feats=True):
         bd = pk.ln_bound(dn[1], HW)
         h = resblock_infer(y, rb, pk, bd, (sc, sh))
         pre = None
-        bound = pk.ln_bound(rb.ln2, HW, bd)
+        bound = pk.ln_bound(rb.ln2, HW, (dn[1], HW))
         feats.append(h)
     # x.view(B,-1) of the NCHW tensor (v2:236): instead of transposing 33 MB of activations per batch, the columns of the
     # two 512 x 32768 head weights are permuted to NHWC order once per weight version

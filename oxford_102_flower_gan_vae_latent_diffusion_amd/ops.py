@@ -543,15 +543,31 @@ def res_tail_out(y, scale=None, shift=None, s=None, map_=None, saw=None, xres=No
     return (out, att) if save_att else out
 
 
-def attention_fwd(qkv, heads, scale, want_p=False):
-    """qkv (B,H,W,3C) -> merged (B,H,W,C) [channel = i*heads + head], optionally P (B,heads,HW,HW). See fl_attention_fwd."""
+def attention_fwd(qkv, heads, scale, want_p=False, want_stats=False):
+    """qkv (B,H,W,3C) -> merged (B,H,W,C) [channel = i*heads + head], optionally P (B,heads,HW,HW) and / or the row statistics
+    (B,heads,HW,2) the fused backward recomputes P from. See fl_attention_fwd."""
     _chk(qkv)
     B, H, W, C3 = qkv.shape
     C, HW = C3 // 3, H * W
     out = new((B, H, W, C), qkv)
     P = new((B, heads, HW, HW), qkv) if want_p else None
-    _lib.call("fl_attention_fwd", _p(qkv), _p(out), _p(P), B, HW, C, int(heads), float(scale), _stream())
-    return (out, P) if want_p else out
+    st = new((B, heads, HW, 2), qkv) if want_stats else None
+    _lib.call("fl_attention_fwd", _p(qkv), _p(out), _p(P), _p(st), B, HW, C, int(heads), float(scale), _stream())
+    res = (out,) + ((P,) if want_p else ()) + ((st,) if want_stats else ())
+    return res if len(res) > 1 else out
+
+
+def attention_bwd(qkv, merged, dmerged, stats, heads, scale):
+    """gradient of attention_fwd w.r.t. qkv (same layout) from the gradient of `merged`; stats from attention_fwd(want_stats=True)."""
+    _chk(qkv, merged, dmerged, stats)
+    B, H, W, C3 = qkv.shape
+    C, HW = C3 // 3, H * W
+    dqkv = torch.empty_like(qkv)
+    n = _lib.load().fl_attention_bwd_workspace_bytes(B, HW, int(heads))
+    ws = workspace(n, qkv.device)
+    _lib.call("fl_attention_bwd", _p(qkv), _p(merged), _p(dmerged), _p(stats), _p(dqkv), B, HW, C, int(heads), float(scale),
+              ctypes.c_void_p(ws.data_ptr()), n, _stream())
+    return dqkv
 
 
 def attention_ok(HW, C, heads):

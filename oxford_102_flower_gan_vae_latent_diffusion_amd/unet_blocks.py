@@ -95,7 +95,9 @@ class UNetAttentionBlock(nn.Module):
         qkv = ops.conv2d_fwd(xn, self._pk.conv(self.qkv), self.qkv.bias.detach(), 1, 0)
         scale = float(d) ** -0.5
         if ops.attention_ok(HW, C, nh):
-            merged, P = ops.attention_fwd(qkv, nh, scale, want_p=True)  # fused forward; P kept for the backward
+            # fused forward; the backward recomputes the probabilities from Q, K and the row statistics (max, sum of exp):
+            # no (B, heads, HW, HW) tensor is kept (268 MB at B=256, C=128, 16x16)
+            merged, P = ops.attention_fwd(qkv, nh, scale, want_stats=True)
         else:
             o = torch.empty(B, nh, HW, d, dtype=torch.float32, device=xh.device)
             P = torch.empty(B, nh, HW, HW, dtype=torch.float32, device=xh.device)
@@ -123,6 +125,10 @@ class UNetAttentionBlock(nn.Module):
         G["proj.weight"] = ops.unpack_conv_weight(ops.conv2d_wgrad(dy, merged, 1, 1, 1, 0), C, C, 1, 1)
         G["proj.bias"] = ops.colsum(_c2(dy))
         dmerged = ops.conv2d_dgrad(dy, self._pk.conv(self.proj), (H, W), 1, 0)
+        if ops.attention_ok(HW, C, nh):
+            # dQ / dK / dV of every (image, head) in two launches (fl_attention_bwd); `P` holds the forward's row statistics
+            dqkv = ops.attention_bwd(qkv, merged, dmerged, P, nh, scale)
+            return self._train_bwd_tail(G, dqkv, dy, xh, gn, xn, (H, W), C, need_in)
         do = ops.unpack_conv_weight(dmerged.view(B, HW, d, nh), B, nh, HW, d)   # inverse of the head merge: (B,nh,HW,d)
         dqkv = torch.empty_like(qkv)
         for b in range(B):
@@ -141,6 +147,10 @@ class UNetAttentionBlock(nn.Module):
                          out=_flat_from(dqkv, base + h * d), ldc=3 * C)
                 ops.gemm(ds, q, HW, d, HW, a_layout=ops.KS, b_layout=ops.KS, lda=HW, ldb=3 * C,
                          out=_flat_from(dqkv, base + C + h * d), ldc=3 * C)
+        return self._train_bwd_tail(G, dqkv, dy, xh, gn, xn, (H, W), C, need_in)
+
+    def _train_bwd_tail(self, G, dqkv, dy, xh, gn, xn, hw, C, need_in):
+        H, W = hw
         G["qkv.weight"] = ops.unpack_conv_weight(ops.conv2d_wgrad(dqkv, xn, 1, 1, 1, 0), 3 * C, C, 1, 1)
         G["qkv.bias"] = ops.colsum(_c2(dqkv))
         dxn = ops.conv2d_dgrad(dqkv, self._pk.conv(self.qkv), (H, W), 1, 0)

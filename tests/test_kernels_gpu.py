@@ -774,3 +774,26 @@ def test_f16x2_linear_long_reduction(dev, M, N, K, nb):
     y2 = ops.linear_fwd_f16x2(xd, wh, N, bd, n_block=N, x_amax=ops.absmax(xd))
     assert torch.equal(y2, y.to(dev)) if nb != N else True     # deterministic, layout-independent
     assert not ops.linear_f16x2_ok(100, N, K) and not ops.linear_f16x2_ok(M, 96, K)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64, 4), (3, 16, 16, 128, 8), (1, 8, 4, 96, 4)])
+def test_fused_attention_backward_vs_autograd(dev, shape):
+    """fl_attention_bwd (dQ kernel + dK / dV kernel, probabilities recomputed from the forward's row statistics, no HW x HW tensor
+    in HBM) against torch fp64 autograd of softmax(scale Q K^T) V with the d-major head merge of v2:456-457; head dims 16, 16, 24."""
+    B, H, W, C, nh = shape
+    HW, d = H * W, C // nh
+    g = torch.Generator().manual_seed(B * 100 + C)
+    qkv = torch.randn(B, H, W, 3 * C, generator=g)
+    dmerged = torch.randn(B, H, W, C, generator=g)
+    scale = float(d) ** -0.5
+    q64 = qkv.double().requires_grad_(True)
+    t = q64.reshape(B, HW, 3, nh, d).permute(2, 0, 3, 1, 4)                      # (3, B, nh, HW, d)
+    att = torch.softmax(scale * t[0] @ t[1].transpose(-1, -2), dim=-1) @ t[2]     # (B, nh, HW, d)
+    merged_ref = att.permute(0, 2, 3, 1).reshape(B, H, W, C)                      # channel = i * heads + head
+    (merged_ref * dmerged.double()).sum().backward()
+    qd = qkv.to(dev)
+    merged, st = ops.attention_fwd(qd, nh, scale, want_stats=True)
+    close(merged, merged_ref.detach(), 2e-5)
+    dq = ops.attention_bwd(qd, merged, dmerged.to(dev), st, nh, scale)
+    for which, name in enumerate(("dQ", "dK", "dV")):
+        close(dq[..., which * C:(which + 1) * C], q64.grad[..., which * C:(which + 1) * C], 3e-5)   # dQ, dK, dV

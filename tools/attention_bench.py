@@ -25,7 +25,13 @@ with torch.no_grad():
     loop8 = t(lambda: blk.forward_nhwc(xs), 3)
     ops.attention_ok = ok
     err = float((y1[:8] - y0).abs().max() / y0.abs().max())
+    # fused backward: dQ kernel + dK / dV kernel (probabilities recomputed; QK^T, dP twice, dQ, dK, dV: 7 contractions)
+    merged, st = ops.attention_fwd(qkv, nh, 32 ** -0.5, want_stats=True)
+    dm = torch.empty_like(merged); ops.philox_fill(dm, 5)
+    bwd = t(lambda: ops.attention_bwd(qkv, merged, dm, st, nh, 32 ** -0.5), 20)
 fl = 4.0 * B * nh * (H * H) ** 2 * (C // nh)  # QK^T + PV
+print("fused attention backward: %.3f ms = %.1f TFLOP/s executed (7 contractions of 2*HW*HW*d; 5 algorithmic: %.1f TFLOP/s)" %
+      (bwd, 7 * fl / 2 / bwd / 1e9, 5 * fl / 2 / bwd / 1e9))
 print("fused attention core (B=%d, %d heads, d=%d, %d tokens): %.3f ms = %.1f TFLOP/s (exact fp32 MFMA); whole block %.3f ms; "
       "loop path at B=8: %.2f ms (x32 = %.0f ms at B=256); fused vs loops max rel diff %.2e" %
       (B, nh, C // nh, H * H, core, fl / core / 1e9, full, loop8, loop8 * 32, err))
