@@ -52,9 +52,87 @@ struct H2Args {
   const float* pre_shift;
   int Cin, Cout, M, tiles_n, ntiles, act;
   float act_param;
+  // in-kernel finish of the fused LayerNorm2d statistics (what conv_inorm_finalize does in a launch of its own), possible where
+  // a block's tile holds whole images: fin = 1: H*W == 64, a wave's 64-row slab IS an image; fin = 2: H*W == 256 == the tile, the
+  // block's four slabs meet in LDS. Same arithmetic in the same order (doubles): bit-identical scale / shift.
+  int fin;
+  const float* ln_w;
+  const float* ln_b;
+  float eps;
+  float* scale;
+  float* shift;
+  float* mean;
+  float* rstd;
 };
 
 using fl::swish_fast;
+
+// per-(image, channel) LayerNorm2d scale / shift from (sum y, sum y^2) over HW pixels: conv_inorm_finalize's arithmetic
+__device__ __forceinline__ void h2_finish_stats(const H2Args& g, int img, int col, double s1, double s2, int HW) {
+  const double m = s1 / HW;
+  double var = s2 / HW - m * m;
+  if (var < 0.0) var = 0.0;
+  const float r = (float)(1.0 / sqrt(var + (double)g.eps));
+  const float sc = r * (g.ln_w ? g.ln_w[col] : 1.f);
+  const size_t i = (size_t)img * g.Cout + col;
+  g.scale[i] = sc;
+  g.shift[i] = (g.ln_b ? g.ln_b[col] : 0.f) - (float)m * sc;
+  if (g.mean) g.mean[i] = (float)m;
+  if (g.rstd) g.rstd[i] = r;
+}
+// epilogue tail shared by both conv kernels: st1 / st2 = this lane's column sums over the wave's 64 rows (two 32-column tiles)
+__device__ __forceinline__ void h2_stats_tail(const H2Args& g, const float (&st1)[2], const float (&st2)[2], int tile_m0, int tile_n0,
+                                              int wr, int wc, int li, int lh, char* smem) {
+  if (!g.stats && !g.fin) return;
+  float a[2], b[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    a[tn] = st1[tn] + __shfl_xor(st1[tn], 32, 64);
+    b[tn] = st2[tn] + __shfl_xor(st2[tn], 32, 64);
+  }
+  if (g.fin == 1) {
+    const int img = (tile_m0 + wr * 64) / 64;
+    if (lh == 0) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) h2_finish_stats(g, img, tile_n0 + wc * 64 + tn * 32 + li, (double)a[tn], (double)b[tn], 64);
+    }
+  } else if (g.fin == 2) {
+    float* ex = reinterpret_cast<float*>(smem);  // [slab 4][sum | sum of squares][128 columns]
+    __syncthreads();                             // every wave has left the main loop: the tile buffers are free
+    if (lh == 0) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        ex[(wr * 2) * 128 + wc * 64 + tn * 32 + li] = a[tn];
+        ex[(wr * 2 + 1) * 128 + wc * 64 + tn * 32 + li] = b[tn];
+      }
+    }
+    __syncthreads();
+    if (wr == 0 && lh == 0) {
+      const int img = tile_m0 / 256;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int c = wc * 64 + tn * 32 + li;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+          s1 += (double)ex[(sl * 2) * 128 + c];
+          s2 += (double)ex[(sl * 2 + 1) * 128 + c];
+        }
+        h2_finish_stats(g, img, tile_n0 + c, s1, s2, 256);
+      }
+    }
+  } else {
+    const int grp = (tile_m0 + wr * 64) / 64;
+    if (lh == 0) {
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int col = tile_n0 + wc * 64 + tn * 32 + li;
+        g.stats[((size_t)grp * 2) * g.Cout + col] = a[tn];
+        g.stats[((size_t)grp * 2 + 1) * g.Cout + col] = b[tn];
+      }
+    }
+  }
+}
 
 __device__ __forceinline__ int scale_exp_from_amax(unsigned bits) {
   const int E = (int)((bits >> 23) & 0xffu);
@@ -371,20 +449,9 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
       }
     }
   }
-  // fused LayerNorm2d statistics: this wave's 64 rows lie in one image (H*W % 64 == 0): one slab of (sum y, sum y^2)
-  if (g.stats) {
-    const int grp = (tile_m0 + wr * 64) / 64;
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const float a = st1[tn] + __shfl_xor(st1[tn], 32, 64);
-      const float b = st2[tn] + __shfl_xor(st2[tn], 32, 64);
-      const int col = tile_n0 + wc * 64 + tn * 32 + li;
-      if (lh == 0) {
-        g.stats[((size_t)grp * 2) * g.Cout + col] = a;
-        g.stats[((size_t)grp * 2 + 1) * g.Cout + col] = b;
-      }
-    }
-  }
+  // fused LayerNorm2d statistics: this wave's 64 rows lie in one image (H*W % 64 == 0): one slab of (sum y, sum y^2) - or,
+  // where the tile holds whole images, the finished scale / shift
+  h2_stats_tail(g, st1, st2, tile_m0, tile_n0, wr, wc, li, lh, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -649,19 +716,7 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
       }
     }
   }
-  if (g.stats) {
-    const int grp_i = (tile_m0 + wr * 64) / 64;
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const float a = st1[tn] + __shfl_xor(st1[tn], 32, 64);
-      const float b = st2[tn] + __shfl_xor(st2[tn], 32, 64);
-      const int col = tile_n0 + wc * 64 + tn * 32 + li;
-      if (lh == 0) {
-        g.stats[((size_t)grp_i * 2) * g.Cout + col] = a;
-        g.stats[((size_t)grp_i * 2 + 1) * g.Cout + col] = b;
-      }
-    }
-  }
+  h2_stats_tail(g, st1, st2, tile_m0, tile_n0, wr, wc, li, lh, smem);
 }
 
 // ---- weight pack: fp32 [N][K] -> header + [16-k group][32-col tile][piece h|l][lane][8 halfs]
@@ -929,8 +984,13 @@ int conv_h2_lds_bytes(int ksize, int Win, int Cin, bool pre) {
 
 int launch_conv_h2(const float* x, const void* wpack, const float* bias, float* y, float* stats, const unsigned* a_amax,
                    int a_exp, const float* pre_scale, const float* pre_shift, int B, int H, int W, int Cin, int Cout, int ksize,
-                   int act, float act_param, hipStream_t s) {
+                   int act, float act_param, const H2Finish* fin, int* finished, hipStream_t s) {
   H2Args g;
+  g.fin = 0;
+  g.ln_w = g.ln_b = nullptr;
+  g.scale = g.shift = g.mean = g.rstd = nullptr;
+  g.eps = 0.f;
+  if (finished) *finished = 0;
   g.pre_scale = pre_scale; g.pre_shift = pre_shift;
   g.Cin = Cin; g.Cout = Cout; g.tiles_n = Cout / 128; g.act = act; g.act_param = act_param;
   g.a_amax = a_amax; g.a_exp = a_exp;
@@ -939,6 +999,15 @@ int launch_conv_h2(const float* x, const void* wpack, const float* bias, float* 
   const int bm = ksize == 3 ? h2_bm(W, Cin, pre_scale != nullptr, g.M, Cout) : 256;
   const int pre_b = pre_scale ? h2_pre_bytes(ksize, ksize == 3 ? W : W / 2, Cin, bm) : 0;
   g.ntiles = (g.M / bm) * g.tiles_n;
+  if (fin && stats) {
+    const int HWo = ksize == 3 ? H * W : (H / 2) * (W / 2);
+    g.fin = HWo == 64 ? 1 : (HWo == 256 && bm == 256 ? 2 : 0);
+    if (g.fin) {
+      g.ln_w = fin->ln_w; g.ln_b = fin->ln_b; g.eps = fin->eps;
+      g.scale = fin->scale; g.shift = fin->shift; g.mean = fin->mean; g.rstd = fin->rstd;
+      if (finished) *finished = 1;
+    }
+  }
   const int blocks = g.ntiles;
   static std::once_flag once;
   std::call_once(once, [] { h2_set_attr<32>(); h2_set_attr<16>(); h2_set_attr<8>(); });
@@ -1101,9 +1170,12 @@ int fl_conv2d_fwd_f16x2(const float* x, const void* wpack, const float* bias, fl
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float* part = stats ? reinterpret_cast<float*>(ws) : nullptr;
+  fl::H2Finish fin;
+  fin.ln_w = ln_w; fin.ln_b = ln_b; fin.eps = eps; fin.scale = scale; fin.shift = shift; fin.mean = mean; fin.rstd = rstd;
+  int finished = 0;
   const int rc = fl::launch_conv_h2(x, wpack, bias, y, part, reinterpret_cast<const unsigned*>(x_amax), x_exp, pre_scale, pre_shift, B, H,
-                                    W, Cin, Cout, kh, act, act_param, s);
-  if (rc || !stats) return rc;
+                                    W, Cin, Cout, kh, act, act_param, stats ? &fin : nullptr, &finished, s);
+  if (rc || !stats || finished) return rc;  // (finished: the conv kernel wrote scale / shift itself: its tiles hold whole images)
   return fl::launch_conv_inorm_finalize(part, ln_w, ln_b, eps, scale, shift, mean, rstd, B, HW, Cout, HW / 64, s);
 }
 

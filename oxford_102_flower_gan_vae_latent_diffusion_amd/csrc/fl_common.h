@@ -103,9 +103,20 @@ int launch_conv_inorm_finalize(const float* partial, const float* ln_w, const fl
 // f16x2 split math (conv_h2.hip): 3x3 s1 p1 conv, weights packed once (header + fp16 h|l fragments)
 bool conv3x3_h2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 bool conv4x4s2_h2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+// LayerNorm2d finish (scale / shift from the fused statistics) done inside the conv kernel where its tiles hold whole images;
+// *finished = 0 when the caller still has to run launch_conv_inorm_finalize on `stats`
+struct H2Finish {
+  const float* ln_w;
+  const float* ln_b;
+  float eps;
+  float* scale;
+  float* shift;
+  float* mean;
+  float* rstd;
+};
 int launch_conv_h2(const float* x, const void* wpack, const float* bias, float* y, float* stats, const unsigned* a_amax,
                    int a_exp, const float* pre_scale, const float* pre_shift, int B, int H, int W, int Cin, int Cout, int ksize,
-                   int act, float act_param, hipStream_t s);
+                   int act, float act_param, const H2Finish* fin, int* finished, hipStream_t s);
 int conv_h2_lds_bytes(int ksize, int Win, int Cin, bool pre);
 size_t pack_weight_f16x2_bytes(int N, int K);
 int pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, hipStream_t s);
