@@ -132,7 +132,7 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
  * >= max|x|, kept by the kernel that produced x) into [2^14,2^15). |x| 2^e >= 65520 yields NaN outputs (loud).
  * Needs Cout % 128 == 0 and: 3x3 H == W in {8,16,32}, Cin % 32 == 0, B*H*W % 128 == 0 (256-pixel tiles, one 8-wave block per
  * CU; 128-pixel tiles with 4 waves when only that divides - FL_H2_BM=128 forces them: measured equal); 4x4 H == W in
- * {16,32,64}, Cin % 8 == 0, B*Ho*Wo % 256 == 0 (fl_conv2d_fwd_f16x2_applicable).
+ * {16,32,64}, Cin % 16 == 0, B*Ho*Wo % 256 == 0 (fl_conv2d_fwd_f16x2_applicable).
  * scale != NULL adds the fused LayerNorm2d statistics of fl_conv2d_fwd_instnorm (same outputs and workspace).
  * pre_scale / pre_shift ([B][Cin], both or neither): the conv consumes swish(x * pre_scale[b,c] + pre_shift[b,c]) - the
  * producer's LayerNorm2d-apply + Swish (v2:163-164, v2:193-194) fused into the halo staging, so that pass never

@@ -36,6 +36,12 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+// FL_H2_ILV=0: the round-2 main loops ([DMA, fragment reads, 12 MFMAs] per tap, staging in bursts) - kept for same-box A/B
+// timing only (tools/build_variant_lib.sh)
+#ifndef FL_H2_ILV
+#define FL_H2_ILV 1
+#endif
+
 constexpr int H2_HDR = 256;  // bytes in front of the weight fragments: [0] amax bits, [1] 2^-e_w (float)
 
 struct H2Args {
@@ -140,6 +146,17 @@ __device__ __forceinline__ int scale_exp_from_amax(unsigned bits) {
   e = e > 100 ? 100 : (e < -100 ? -100 : e);
   return e;
 }
+
+// staging schedule of the 3x3 kernel's main loop: step q of nstep goes to MFMA gap 1 + 39 q / nstep of the 40 gaps of taps 3..7
+constexpr int h2_step_pos(int q, int nstep) { return 1 + (q * 39) / nstep; }
+constexpr int h2_step_at(int G, int nstep) {
+  for (int q = 0; q < nstep; ++q)
+    if (h2_step_pos(q, nstep) == G) return q;
+  return -1;
+}
+// item j's pre-op coefficients are read in the last gap of the k group BEFORE its first element (-1: the group before the window),
+// so that the group's closing lgkmcnt(0) covers them and no wait lands among the MFMAs
+constexpr int h2_ssload_pos(int j, int nst) { return 8 * (h2_step_pos(4 * j, 4 * nst) / 8) - 1; }
 
 template <int W, int BM_ = 256>
 struct H2Geom {
@@ -277,6 +294,43 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
     stage_item(std::integral_constant<int, 4>{}, buf, c);
   };
 
+  // The same item, cut into slots for the main loop (FL_H2_ILV): element e of item j is staging step q = 4 j + e; the chunk's
+  // 4 NST steps are dealt over the 40 MFMA gaps of taps 3..7 (h2_step_at), an item's pre-op coefficients are read at the end
+  // of the tap before its first element and its two ds_write_b64 follow its last. Pieces wait in registers (sth / stl) in between.
+  f32x4v ssc[NST], ssh[NST];
+  f16x4_t sth[NST], stl[NST];
+#define FL_SS_CH 16
+  auto stage_slot = [&](auto tc, auto pc, int buf, int c) {
+    constexpr int T = decltype(tc)::value, p = decltype(pc)::value;
+    if constexpr (T >= 2 && T <= 7) {
+      constexpr int G = (T - 3) * 8 + p;
+      constexpr int q = G >= 0 ? h2_step_at(G, 4 * NST) : -1;
+      if constexpr (PRE) {
+#define FL_SSLOAD(jl)                                                                                 \
+        if constexpr (jl < NST && h2_ssload_pos(jl < NST ? jl : 0, NST) == G) {                       \
+          ssc[jl < NST ? jl : 0] = *reinterpret_cast<const f32x4v*>(ss + ssoff[jl < NST ? jl : 0] + c * FL_SS_CH);               \
+          ssh[jl < NST ? jl : 0] = *reinterpret_cast<const f32x4v*>(ss + NI * Cin + ssoff[jl < NST ? jl : 0] + c * FL_SS_CH);    \
+        }
+        FL_SSLOAD(0) FL_SSLOAD(1) FL_SSLOAD(2) FL_SSLOAD(3) FL_SSLOAD(4) FL_SSLOAD(5)
+#undef FL_SSLOAD
+      }
+      if constexpr (q >= 0) {
+        constexpr int j = q >> 2, e = q & 3;
+        float v = stg[j][e];
+        if constexpr (PRE) v = swish_fast(v * ssc[j][e] + ssh[j][e]);
+        const float X = ((vmask >> j) & 1u) ? v * sa : 0.f;
+        const _Float16 hh = (_Float16)X;
+        sth[j][e] = hh;
+        stl[j][e] = (_Float16)(X - (float)hh);
+        if constexpr (e == 3) {
+          char* dst = smem + buf * ABUF_B;
+          *reinterpret_cast<f16x4_t*>(dst + sdst[j]) = sth[j];
+          *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = stl[j];
+        }
+      }
+    }
+  };
+
   // ---- A fragment addresses (bytes inside a plane): tile row r -> halo pixel of tap (0,0); tap (dy,dx) adds dy*RPB + dx*PXB
   int abase[2];
 #pragma unroll
@@ -371,10 +425,43 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
 
   // one tap: DMA three taps ahead into the slot this tap's fragments came from, fragments of the next tap under this
   // tap's MFMAs, then [counted vmcnt: the DMA of tap t+2 has landed] + lgkmcnt(0) + barrier
+  // FL_H2_ILV (default): the tap OPENS with MFMAs. The r02 order [weight DMA, 8 fragment reads, 12 MFMAs] left the matrix pipe
+  // empty behind every barrier while both waves of a SIMD issued their DMA piece (60-180 cycles) and their reads; now the
+  // first two MFMAs go out at once, one fragment read of the next tap follows each of the next eight, and the DMA piece (and
+  // the halo loads of tap 0) sit behind MFMA 9. Every step is pinned by a sched_barrier: the order below is the issue order.
   auto tap = [&](auto tap_c, Frags& cur, Frags& nxt, int c) {
     constexpr int T = decltype(tap_c)::value;
     constexpr int T3 = (T + 3) % 9, C3 = (T + 3) / 9;        // tap t+3
     constexpr int T1 = (T + 1) % 9, C1 = (T + 1) / 9;        // tap t+1
+#if FL_H2_ILV
+    const char* An = smem + ((c + C1) & 1) * ABUF_B + (T1 / 3) * RPB + (T1 % 3) * PXB;
+    const char* Bn = smem + bfrag + (T1 % 3) * SLOT_B;
+    auto MF = [&](auto ic) {  // MFMA i of the tap's twelve: pieces l*h, h*l, h*h (smallest first) x (tm, tn)
+      constexpr int i = decltype(ic)::value, piece = i >> 2, tm = (i >> 1) & 1, tn = i & 1;
+      constexpr int pa = piece == 0 ? 1 : 0, pb = piece == 1 ? 1 : 0;
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[tm][pa], cur.b[tn][pb], acc[tm][tn], 0, 0, 0);
+    };
+    auto RD = [&](auto jc) {  // fragment read j of the next tap's eight: B first (its DMA landed a tap ago)
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j < 4) nxt.b[j >> 1][j & 1] = *reinterpret_cast<const f16x8_t*>(Bn + (j >> 1) * 2048 + (j & 1) * 1024);
+      else nxt.a[(j - 4) >> 1][j & 1] = *reinterpret_cast<const f16x8_t*>(An + abase[(j - 4) >> 1] + (j & 1) * PLANE_B);
+    };
+#define FL_I(n) std::integral_constant<int, n>{}
+#define FL_SB __builtin_amdgcn_sched_barrier(0)
+    MF(FL_I(0)); FL_SB; MF(FL_I(1)); FL_SB;
+    // per MFMA of the middle eight: one fragment read of the next tap and - in taps 3..7 - this slot's share of the NEXT chunk's
+    // staging (stage_slot below: the items' elements dealt over 40 slots, so no tap carries more VALU work than its MFMAs cover)
+    const int cn = c + 1 < nC ? c + 1 : c, bn = (c + 1) & 1;
+#define FL_STEP(p) RD(FL_I(p)); FL_SB; stage_slot(tap_c, FL_I(p), bn, cn); FL_SB; MF(FL_I(p + 2)); FL_SB;
+    FL_STEP(0) FL_STEP(1) FL_STEP(2) FL_STEP(3) FL_STEP(4) FL_STEP(5) FL_STEP(6) FL_STEP(7)
+#undef FL_STEP
+    dma_tap(c + C3, T3, T % 3);
+    if constexpr (T == 0) stage_load(cn);
+    FL_SB;
+    MF(FL_I(10)); FL_SB; MF(FL_I(11)); FL_SB;
+#undef FL_I
+#undef FL_SB
+#else
     dma_tap(c + C3, T3, T % 3);
     if constexpr (T == 0) stage_load(c + 1 < nC ? c + 1 : c);
     frag_load(nxt, (c + C1) & 1, (T1 / 3) * RPB + (T1 % 3) * PXB, T1 % 3);
@@ -390,6 +477,7 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
     } else {
       mfma12(cur, std::true_type{});
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (T == 0 || T == 1) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST + PPW) : "memory");
@@ -513,7 +601,8 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
   unsigned vmask = 0u;
 #pragma unroll
   for (int j = 0; j < NST; ++j) {
-    const int i = tid + NT * j;
+    // threads past the last item repeat item i - ITEMS (same bytes to the same place as its owner): branch-free staging
+    const int i0 = tid + NT * j, i = i0 < ITEMS ? i0 : i0 - ITEMS;
     const int pix = i >> 1, c4 = i & 1;
     const int nl = pix / (HR * HC), rem = pix - nl * (HR * HC);
     const int hy = rem / HC, hx = rem - hy * HC;
@@ -534,6 +623,95 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
     __syncthreads();
   }
 
+#if FL_H2_ILV
+  // Halo loads cover TWO chunks (16 channels = 64 contiguous bytes per pixel, two 16-byte loads per thread issued back to back):
+  // a chunk's 8 channels alone are 32-byte pieces of a pixel row, and fetching a row's two halves a chunk apart cost down1 1.6x
+  // its algorithmic traffic. stg[0][j] = channels 0..7 of the pair (an even chunk), stg[1][j] = channels 8..15 (the odd chunk).
+  f32x4v stg[2][NST];
+  auto stage_load = [&](int sc) {  // sc: chunk pair
+    const float* xc = g.x + sc * 16;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const float* p = xc + goff[j];
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:32"
+                   : "=&v"(stg[0][j]), "=&v"(stg[1][j]) : "v"(p) : "memory");
+    }
+  };
+#define FL_STAGE_WAIT4(N)                                                                                                    \
+  do {                                                                                                                       \
+    if constexpr (NST == 5)                                                                                                  \
+      asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                 \
+                   : "+v"(stg[0][0]), "+v"(stg[0][1]), "+v"(stg[0][2]), "+v"(stg[0][3]), "+v"(stg[0][4]),                       \
+                     "+v"(stg[1][0]), "+v"(stg[1][1]), "+v"(stg[1][2]), "+v"(stg[1][3]), "+v"(stg[1][4])                        \
+                   ::"memory");                                                                                              \
+    else                                                                                                                     \
+      asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                 \
+                   : "+v"(stg[0][0]), "+v"(stg[0][1]), "+v"(stg[0][2]), "+v"(stg[0][3]), "+v"(stg[0][4]), "+v"(stg[0][NST - 1]), \
+                     "+v"(stg[1][0]), "+v"(stg[1][1]), "+v"(stg[1][2]), "+v"(stg[1][3]), "+v"(stg[1][4]), "+v"(stg[1][NST - 1])  \
+                   ::"memory");                                                                                              \
+  } while (0)
+  auto stage_store = [&](int buf, int c) {  // prologue only: chunk c (0) = the even half of the pair in the staging registers
+    char* dst = smem + buf * ABUF_B;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      if (sdst[j] < 0) continue;
+      const bool ok = (vmask >> j) & 1u;
+      f32x4v v = stg[0][j];
+      if constexpr (PRE) {
+        const f32x4v sc = *reinterpret_cast<const f32x4v*>(ss + ssoff[j] + c * 8);
+        const f32x4v sh = *reinterpret_cast<const f32x4v*>(ss + NI * Cin + ssoff[j] + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = swish_fast(v[e] * sc[e] + sh[e]);
+      }
+      f16x4_t h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float X = ok ? v[e] * sa : 0.f;
+        const _Float16 hh = (_Float16)X;
+        h[e] = hh;
+        l[e] = (_Float16)(X - (float)hh);
+      }
+      *reinterpret_cast<f16x4_t*>(dst + sdst[j]) = h;
+      *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = l;
+    }
+  };
+  // main-loop staging in slots (as in the 3x3 kernel): while chunk c runs, chunk c + 1 = half (c + 1) & 1 of the pair in the
+  // registers is converted element by element in the 40 MFMA gaps of k groups 2..6 and written to the other buffer
+  f32x4v ssc[NST], ssh[NST];
+  f16x4_t sth[NST], stl[NST];
+#undef FL_SS_CH
+#define FL_SS_CH 8
+  auto stage_slot = [&](auto tc, auto pc, auto hc, int buf, int c) {
+    constexpr int T = decltype(tc)::value, p = decltype(pc)::value, HALF = decltype(hc)::value;
+    if constexpr (T >= 1 && T <= 6) {
+      constexpr int G = (T - 2) * 8 + p;
+      constexpr int q = G >= 0 ? h2_step_at(G, 4 * NST) : -1;
+      if constexpr (PRE) {
+#define FL_SSLOAD(jl)                                                                                 \
+        if constexpr (jl < NST && h2_ssload_pos(jl < NST ? jl : 0, NST) == G) {                       \
+          ssc[jl < NST ? jl : 0] = *reinterpret_cast<const f32x4v*>(ss + ssoff[jl < NST ? jl : 0] + c * FL_SS_CH);               \
+          ssh[jl < NST ? jl : 0] = *reinterpret_cast<const f32x4v*>(ss + NI * Cin + ssoff[jl < NST ? jl : 0] + c * FL_SS_CH);    \
+        }
+        FL_SSLOAD(0) FL_SSLOAD(1) FL_SSLOAD(2) FL_SSLOAD(3) FL_SSLOAD(4) FL_SSLOAD(5)
+#undef FL_SSLOAD
+      }
+      if constexpr (q >= 0) {
+        constexpr int j = q >> 2, e = q & 3;
+        float v = stg[HALF][j][e];
+        if constexpr (PRE) v = swish_fast(v * ssc[j][e] + ssh[j][e]);
+        const float X = ((vmask >> j) & 1u) ? v * sa : 0.f;
+        const _Float16 hh = (_Float16)X;
+        sth[j][e] = hh;
+        stl[j][e] = (_Float16)(X - (float)hh);
+        if constexpr (e == 3) {
+          char* dst = smem + buf * ABUF_B;
+          *reinterpret_cast<f16x4_t*>(dst + sdst[j]) = sth[j];
+          *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = stl[j];
+        }
+      }
+    }
+  };
+#else
   f32x4v stg[NST];
   auto stage_load = [&](int c) {
     const float* xc = g.x + c * 8;
@@ -576,6 +754,8 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
       *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = l;
     }
   };
+
+#endif
 
   // A fragment address of k group (ky, kp): this lane's tap is (ky, 2 kp + lh) -> column parity lh, entry ox + kp
   int abase[2];
@@ -634,6 +814,89 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
     __builtin_amdgcn_s_setprio(0);
   };
 
+#if FL_H2_ILV
+  // ---- prologue: chunk pair 0 loaded, its even half staged, k groups 0..3 in the ring, fragments of group 0 in registers
+  stage_load(0);
+  dma_grp(0, 0, 0);
+  dma_grp(0, 1, 1);
+  dma_grp(0, 2, 2);
+  dma_grp(0, 3, 3);
+  FL_STAGE_WAIT4(4);
+  stage_store(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  Frags fA, fB;
+  frag_load(fA, 0, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // one k group, MFMA first (see conv3x3_h2_kernel): two MFMAs, then per MFMA one fragment read of the next group and a staging
+  // slot, the DMA piece (four groups ahead, into the slot this group's fragments came from) behind MFMA 9 - and, in the last
+  // group of an EVEN chunk c, the halo loads of chunks c + 2 | c + 3 (their registers were last read in group 6).
+  // vmcnt at the end of group t, oldest first: DMA(t+2), DMA(t+3), DMA(t+4) = 2 may stay; the 2 NST halo loads sit behind
+  // DMA(t+4) in group 7 of an even chunk, between DMA(t+3) and DMA(t+4) in group 0 of the odd chunk, and are waited for (with
+  // DMA(t+2), which is younger) at the end of its group 1.
+  auto grp = [&](auto grp_c, auto par_c, Frags& cur, Frags& nxt, int c) {
+    constexpr int T = decltype(grp_c)::value, PAR = decltype(par_c)::value;
+    constexpr int T4 = (T + 4) % 8, C4 = (T + 4) / 8;
+    constexpr int T1 = (T + 1) % 8, C1 = (T + 1) / 8;
+    const char* An = smem + ((c + C1) & 1) * ABUF_B + (T1 >> 1) * RPB + (T1 & 1) * PXB;
+    const char* Bn = smem + bfrag + (T1 % 4) * SLOT_B;
+    auto MF = [&](auto ic) {
+      constexpr int i = decltype(ic)::value, piece = i >> 2, tm = (i >> 1) & 1, tn = i & 1;
+      constexpr int pa = piece == 0 ? 1 : 0, pb = piece == 1 ? 1 : 0;
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[tm][pa], cur.b[tn][pb], acc[tm][tn], 0, 0, 0);
+    };
+    auto RD = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j < 4) nxt.b[j >> 1][j & 1] = *reinterpret_cast<const f16x8_t*>(Bn + (j >> 1) * 2048 + (j & 1) * 1024);
+      else nxt.a[(j - 4) >> 1][j & 1] = *reinterpret_cast<const f16x8_t*>(An + abase[(j - 4) >> 1] + (j & 1) * PLANE_B);
+    };
+    const int cn = c + 1 < nC ? c + 1 : c, bn = (c + 1) & 1;
+#define FL_I(n) std::integral_constant<int, n>{}
+#define FL_SB __builtin_amdgcn_sched_barrier(0)
+#define FL_STEP(p) RD(FL_I(p)); FL_SB; stage_slot(grp_c, FL_I(p), FL_I(1 - PAR), bn, cn); FL_SB; MF(FL_I(p + 2)); FL_SB;
+    MF(FL_I(0)); FL_SB; MF(FL_I(1)); FL_SB;
+    FL_STEP(0) FL_STEP(1) FL_STEP(2) FL_STEP(3) FL_STEP(4) FL_STEP(5) FL_STEP(6) FL_STEP(7)
+    dma_grp(c + C4, T4, T % 4);
+    if constexpr (T == 7 && PAR == 0) stage_load(c + 2 < nC ? (c + 2) >> 1 : (nC - 1) >> 1);
+    FL_SB;
+    MF(FL_I(10)); FL_SB; MF(FL_I(11)); FL_SB;
+#undef FL_STEP
+#undef FL_I
+#undef FL_SB
+    if constexpr ((T == 7 && PAR == 0) || (T == 0 && PAR == 1)) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NST + 2) : "memory");
+    } else if constexpr (T == 1 && PAR == 1) {
+      FL_STAGE_WAIT4(2);
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto chunk = [&](auto par, int c) {  // 8 groups: the register sets alternate and come back to fA
+    grp(std::integral_constant<int, 0>{}, par, fA, fB, c);
+    grp(std::integral_constant<int, 1>{}, par, fB, fA, c);
+    grp(std::integral_constant<int, 2>{}, par, fA, fB, c);
+    grp(std::integral_constant<int, 3>{}, par, fB, fA, c);
+    grp(std::integral_constant<int, 4>{}, par, fA, fB, c);
+    grp(std::integral_constant<int, 5>{}, par, fB, fA, c);
+    grp(std::integral_constant<int, 6>{}, par, fA, fB, c);
+    grp(std::integral_constant<int, 7>{}, par, fB, fA, c);
+  };
+#pragma unroll 1
+  for (int c = 0; c < nC; c += 2) {  // nC is even (Cin % 16 == 0)
+    chunk(std::integral_constant<int, 0>{}, c);
+    chunk(std::integral_constant<int, 1>{}, c + 1);
+  }
+#undef FL_STAGE_WAIT4
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
   // ---- prologue: chunk 0 staged, k groups 0..3 in the ring, fragments of group 0 in registers
   stage_load(0);
   dma_grp(0, 0, 0);
@@ -692,6 +955,8 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
   for (int c = 0; c < nC; ++c) chunk(c);
 #undef FL_STAGE_WAIT4
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#endif
 
   float st1[2], st2[2], bv[2];
   const bool has_act = g.act != FL_ACT_NONE;
@@ -962,7 +1227,7 @@ bool conv3x3_h2_applicable(const float* x, int B, int H, int W, int Cin, int Cou
 }
 
 bool conv4x4s2_h2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
-  if (Cin % 8 || Cout % 128 || (reinterpret_cast<uintptr_t>(x) & 15) || H != W) return false;
+  if (Cin % 16 || Cout % 128 || (reinterpret_cast<uintptr_t>(x) & 15) || H != W) return false;  // halo loads take chunk PAIRS
   if ((long long)B * H * W * Cin >= (1ll << 31)) return false;
   if (kh == 4 && kw == 4 && stride == 2 && pad == 1 && (W == 16 || W == 32 || W == 64)) return ((long long)B * (H / 2) * (W / 2)) % 256 == 0;
   return false;
