@@ -316,6 +316,26 @@ int fl_philox_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, const 
 int fl_philox_randint(int64_t* out, int64_t n, uint64_t seed, uint64_t offset, const int64_t* dev_offset, int hi,
                       fl_stream_t stream);
 int fl_advance_offset(int64_t* dev_offset, int64_t delta, fl_stream_t stream);
+/* The tail of BOTH encoder heads in one launch (csrc/latent_prep.hip; v2:210-221: fc_mu / fc_logvar are Linear -> LayerNorm ->
+ * Swish -> Linear; this is everything behind the first Linear): g = [2][B][K] pre-LayerNorm activations (head 0 = mu, 1 = logvar,
+ * bias included), K in {256, 512}, L % 32 == 0 (fl_encoder_heads_applicable), exact-fp32 MFMA. Outputs mu / logvar [B][L] (either
+ * may be NULL) and, when z != NULL, reparameterize (v2:339-343): z = mu + eps * exp(0.5 * clamp(logvar, -2, 10)) with eps the
+ * N(0,1) numbers fl_philox_fill(mode 0) produces at counter (dev_offset ? *dev_offset : 0). With dev_offset the kernel also moves
+ * the counter on by (B*L + 3) / 4 when its last block finishes: done_counter is a zero-initialised uint32 word it uses (and
+ * re-zeroes) for that. Replaces 9 launches of the frozen-encoder step (2 x [LayerNorm, GEMM, split-K reduce], fill, bump, reparam). */
+int fl_encoder_heads_applicable(int B, int K, int L);
+int fl_encoder_heads_fwd(const float* g, const float* ln_w_mu, const float* ln_b_mu, const float* ln_w_logvar,
+                         const float* ln_b_logvar, float ln_eps, const float* w_mu, const float* b_mu, const float* w_logvar,
+                         const float* b_logvar, float* mu, float* logvar, float* z, uint64_t seed, int64_t* dev_offset,
+                         void* done_counter, int B, int K, int L, fl_stream_t stream);
+/* The draws of one latent-DDPM training step and q_sample in one launch (v2:1260-1261, v2:574-578): t[b] = the number
+ * fl_philox_randint(hi = n_steps) gives at counter base + b, noise = fl_philox_fill(mode 0) at counter base + B (base = offset +
+ * *dev_offset), x_t = sqrt(alpha_bar[t]) z + sqrt(1 - alpha_bar[t]) noise. masks != NULL adds a second, independent draw: n_masks
+ * dropout scales {0, 1/(1-p)} = fl_philox_fill(mode 1) of the stream (mask_seed, mask_offset + *mask_dev_offset). No counter is
+ * moved: the caller bumps them (B + (B*L + 3)/4 and (n_masks + 3)/4), e.g. through fl_program_run's post hook. L % 4 == 0. */
+int fl_diffuse_prep(const float* z, const float* alpha_bar, int n_steps, uint64_t seed, uint64_t offset, const int64_t* dev_offset,
+                    int64_t* t, float* noise, float* xt, int B, int L, float* masks, int64_t n_masks, uint64_t mask_seed,
+                    uint64_t mask_offset, const int64_t* mask_dev_offset, float p, fl_stream_t stream);
 size_t fl_colsum_workspace_bytes(int M, int N);
 /* out = beta*out + alpha * column sums of x (M,N): bias gradients */
 int fl_colsum(const float* x, int64_t ldx, float* out, int M, int N, float alpha, float beta, void* ws, size_t ws_bytes,

@@ -13,6 +13,8 @@ from . import ops
 SW = ops.ACT_SWISH
 # f16x2 split math for the 3x3 ResidualBlock convs of the inference paths (FL_CONV_F16X2=0: the r01 bf16x3 kernels)
 USE_F16X2 = os.environ.get("FL_CONV_F16X2", "1") != "0"
+# FL_FUSED_HEADS=0: the encoder heads' tail and the DDPM step's draws as separate launches (the round-2 chain; same numbers)
+FUSED_HEADS = os.environ.get("FL_FUSED_HEADS", "1") != "0"
 
 
 class PackCache:
@@ -172,6 +174,19 @@ def _head(fc, flat, w0=None):
 def encoder_infer(enc, x, want_feats=True):
     """Encoder.forward (v2:223-239). x (B,3,64,64) NCHW -> mu, logvar (B,latent), [NHWC skip features] (v2:224-235;
     want_feats=False: the list holds None where an activation was fused away - the decoder ignores it, v2:280)."""
+    return _encoder_infer(enc, x, want_feats)[:3]
+
+
+def encoder_latent(enc, x, rng):
+    """z = reparameterize(*Encoder.forward(x)) (v2:1257-1259 / v2:339-343) with the N(0,1) draws taken from `rng` (rng.Philox):
+    where the heads run through the fused tail kernel the draws are made inside it, otherwise by rng.normal - the same numbers."""
+    mu, logvar, _, z = _encoder_infer(enc, x, False, rng)
+    if z is None:
+        z, _ = ops.reparameterize(mu, logvar, rng.normal(mu.shape, mu.device))
+    return z
+
+
+def _encoder_infer(enc, x, want_feats=True, reparam_rng=None):
     pk = enc._pk
     B = x.shape[0]
     h = ops.nchw_to_nhwc(x, 4)
@@ -215,12 +230,22 @@ def encoder_infer(enc, x, want_feats=True):
         wh, bcat = pk.get(("fc_heads_h2",), [enc.fc_mu[0].weight, enc.fc_logvar[0].weight, enc.fc_mu[0].bias,
                                               enc.fc_logvar[0].bias], make)
         g2 = ops.linear_fwd_f16x2(flat, wh, 2 * N1, bcat, n_block=N1, x_amax=bound)
+        fm, fv = enc.fc_mu, enc.fc_logvar
+        if (FUSED_HEADS and ops.encoder_heads_ok(B, N1, fm[3].weight.shape[0]) and fm[3].weight.shape == fv[3].weight.shape
+                and fm[1].eps == fv[1].eps):
+            # LayerNorm -> Swish -> Linear of both heads (and the reparameterisation draws, when asked) in ONE launch
+            mu, lv, z = ops.encoder_heads_fwd(
+                g2, (_d(fm[1].weight), _d(fm[1].bias)), (_d(fv[1].weight), _d(fv[1].bias)), (_d(fm[3].weight), _d(fm[3].bias)),
+                (_d(fv[3].weight), _d(fv[3].bias)), eps=fm[1].eps, want_stats=reparam_rng is None,
+                rng_seed=reparam_rng.seed if reparam_rng is not None else None,
+                rng_state=reparam_rng.state(x.device) if reparam_rng is not None else None)
+            return mu, lv, feats, z
         outs = []
-        for hi, fc in enumerate((enc.fc_mu, enc.fc_logvar)):
+        for hi, fc in enumerate((fm, fv)):
             gh, _, _ = ops.layernorm_fwd(g2[hi], _d(fc[1].weight), _d(fc[1].bias), eps=fc[1].eps, act=SW, save=False)
             outs.append(ops.linear(gh, _d(fc[3].weight), _d(fc[3].bias)))
-        return outs[0], outs[1], feats
-    return _head(enc.fc_mu, flat, perm(enc.fc_mu)), _head(enc.fc_logvar, flat, perm(enc.fc_logvar)), feats
+        return outs[0], outs[1], feats, None
+    return _head(enc.fc_mu, flat, perm(enc.fc_mu)), _head(enc.fc_logvar, flat, perm(enc.fc_logvar)), feats, None
 
 
 def decoder_infer(dec, z):

@@ -432,13 +432,27 @@ class ConditionalUNet(nn.Module):
             self._freq_cache[device] = f
         return f
 
-    def dropout_masks(self, B, device, defer=False):
+    def dropout_masks(self, B, device, defer=False, draw=True):
         """Philox dropout-scale tensors for train mode: (block_masks, head_masks). With one dropout rate everywhere (the
         reference's dropout_rate feeds both nn.Dropout and the attention dropout, v2:503-516) all eight masks are slices of
-        ONE draw: 2 launches instead of 16 in the step's dependent kernel chain; elements stay independent (counter-based)."""
+        ONE draw: 2 launches instead of 16 in the step's dependent kernel chain; elements stay independent (counter-based).
+        draw=False (with defer): nothing is launched - returns (flat buffer to fill, rate, block_masks, head_masks, counters):
+        the caller makes the one draw itself (ops.diffuse_prep); (None, ...) when the rates differ and one draw cannot serve."""
         dims = [block[0].weight.shape[0] for block, _, _ in self.layers]
         heads = [self.attention_layers[i].num_heads for i in range(len(self.layers))]
         rates = {block[2].p for block, _, _ in self.layers} | {self.attention_layers[i].dropout for i in range(len(self.layers))}
+        if not draw:
+            if len(rates) != 1:
+                return (None, 0.0, None, None, 0)
+            sizes = [B * d for d in dims] + [B * h for h in heads]
+            flat = torch.empty((sum(sizes),), dtype=torch.float32, device=device)
+            parts, o = [], 0
+            for n in sizes:
+                parts.append(flat[o:o + n])
+                o += n
+            L = len(dims)
+            return (flat, rates.pop(), [parts[i].view(B, dims[i]) for i in range(L)],
+                    [parts[L + i].view(B, heads[i]) for i in range(L)], self.rng.fill_count(sum(sizes)))
         if len(rates) == 1:
             sizes = [B * d for d in dims] + [B * h for h in heads]
             # defer=True: the caller bumps this stream's counter itself (by the returned count) - see rng.Philox

@@ -743,6 +743,48 @@ def philox_randint(out, seed, hi, offset=0, dev_offset=None):
     return out
 
 
+def encoder_heads_ok(B, K, L):
+    return bool(_lib.load().fl_encoder_heads_applicable(int(B), int(K), int(L)))
+
+
+_heads_done = {}
+
+
+def encoder_heads_fwd(g2, ln_mu, ln_lv, lin_mu, lin_lv, eps=1e-5, want_stats=True, rng_seed=None, rng_state=None):
+    """Both encoder heads behind their first Linear (v2:210-221) in one launch: g2 (2, B, K) -> mu, logvar (B, L) and - with
+    rng_seed - z = reparameterize(mu, logvar) (v2:339-343) on the Philox draws of (rng_seed, *rng_state); the kernel moves the
+    device-resident counter on itself. ln_* = (weight, bias) of the LayerNorms, lin_* = (weight (L, K), bias) of the second Linears."""
+    _chk(g2, *ln_mu, *ln_lv, *lin_mu, *lin_lv, rng_state)
+    _, B, K = g2.shape
+    L = lin_mu[0].shape[0]
+    mu = new((B, L), g2) if want_stats else None
+    lv = new((B, L), g2) if want_stats else None
+    z = new((B, L), g2) if rng_seed is not None else None
+    done = None
+    if z is not None and rng_state is not None:
+        key = (g2.device.type, g2.device.index)
+        done = _heads_done.get(key)
+        if done is None:
+            done = _heads_done[key] = torch.zeros(1, dtype=torch.int32, device=g2.device)
+    _lib.call("fl_encoder_heads_fwd", _p(g2), _p(ln_mu[0]), _p(ln_mu[1]), _p(ln_lv[0]), _p(ln_lv[1]), float(eps), _p(lin_mu[0]),
+              _p(lin_mu[1]), _p(lin_lv[0]), _p(lin_lv[1]), _p(mu), _p(lv), _p(z), int(rng_seed or 0), _p(rng_state), _p(done), B, K, L,
+              _stream())
+    return mu, lv, z
+
+
+def diffuse_prep(z, alpha_bar, n_steps, seed, state, offset=0, masks=None, mask_seed=0, mask_state=None, mask_offset=0, p=0.0):
+    """t, noise, x_t of one latent-DDPM training step (v2:1260-1261 + q_sample v2:574-578) and, optionally, the step's dropout
+    scales in one launch; the draws are those of philox_randint / philox_fill at the same counters (not advanced here)."""
+    _chk(z, alpha_bar, state, masks, mask_state)
+    B, L = z.shape
+    t = torch.empty((B,), dtype=torch.int64, device=z.device)
+    noise, xt = torch.empty_like(z), torch.empty_like(z)
+    _lib.call("fl_diffuse_prep", _p(z), _p(alpha_bar), int(n_steps), int(seed), int(offset), _p(state), _p(t), _p(noise), _p(xt), B, L,
+              _p(masks), masks.numel() if masks is not None else 0, int(mask_seed), int(mask_offset), _p(mask_state), float(p),
+              _stream())
+    return t, noise, xt
+
+
 def advance_offset(dev_offset, delta):
     _lib.call("fl_advance_offset", _p(dev_offset), int(delta), _stream())
 

@@ -180,9 +180,9 @@ class DDPMTrainer:
     @torch.no_grad()
     def encode(self, data, reparam_eps=None):
         """v2:1257-1259 (frozen encoder, eval)."""
+        if reparam_eps is None:   # draws from the autoencoder's Philox stream: made inside the heads' tail kernel where that runs
+            return engine.encoder_latent(self.ae.encoder, data, self.ae.rng)
         mu, logvar, _ = engine.encoder_infer(self.ae.encoder, data, want_feats=False)
-        if reparam_eps is None:
-            reparam_eps = self.ae.rng.normal(mu.shape, mu.device)
         z, _ = ops.reparameterize(mu, logvar, reparam_eps)
         return z
 
@@ -194,6 +194,18 @@ class DDPMTrainer:
         # on the program path the Philox counters of this step's draws are bumped by the program's post hook (the last block
         # to leave) instead of one tiny launch per draw: same numbers (offset = counters consumed so far)
         d_adv = m_adv = 0
+        xt = None
+        want_masks = self.unet.training and block_masks is None and self.unet.dropout_rate > 0
+        if use_prog and t is None and eps is None and engine.FUSED_HEADS and z.shape[1] % 4 == 0:
+            # t, noise, x_t and the dropout scales in ONE launch (same numbers as the draws below, counter for counter)
+            spec = self.unet.dropout_masks(B, z.device, defer=True, draw=False) if want_masks else None
+            flat = spec[0] if spec is not None and spec[0] is not None else None
+            t, eps, xt = ops.diffuse_prep(z, d.alpha_bar, d.n_steps, d.rng.seed, d.rng.state(z.device), masks=flat,
+                                          mask_seed=self.unet.rng.seed, mask_state=self.unet.rng.state(z.device),
+                                          p=spec[1] if flat is not None else 0.0)
+            d_adv = B + d.rng.fill_count(z.numel())
+            if flat is not None:
+                block_masks, head_masks, m_adv = spec[2], spec[3], spec[4]
         if t is None:
             t = d.rng.randint((B,), z.device, d.n_steps, advance=not use_prog)
             d_adv += B
@@ -205,7 +217,8 @@ class DDPMTrainer:
                 block_masks, head_masks, m_adv = self.unet.dropout_masks(B, z.device, defer=True)
             else:
                 block_masks, head_masks = self.unet.dropout_masks(B, z.device)
-        xt = ops.q_sample(z, eps, t, d.alpha_bar)
+        if xt is None:
+            xt = ops.q_sample(z, eps, t, d.alpha_bar)
         if use_prog:
             prog = self._train_program(B, block_masks is not None)
             self._last_tp = prog.programs[-1]   # the optimizer program watches this run's abort word
