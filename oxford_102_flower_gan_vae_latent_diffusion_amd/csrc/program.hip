@@ -411,7 +411,18 @@ __device__ __forceinline__ void gemm_tile(const fl_pjob& jb, int rt, int ct, con
 // quadrant over the whole contraction (no partial tiles to merge) and stores it straight from the accumulators. Against
 // four 32 x 32 tiles: half the operand traffic, no LDS round trip for the partial sums, 128 MFMAs per wave behind one
 // load latency instead of 32 (measured: 4.6 us per 32 x 32 tile -> 7 us per 64 x 64).
-__device__ __forceinline__ void wg64_tile(const fl_pjob& jb, int rt, int ct, const ProgIO& io, float* smem, const bool wt) {
+// the workgroup barrier WITHOUT the memory fence of __syncthreads() (hipcc puts s_waitcnt vmcnt(0) lgkmcnt(0) in front of that
+// one: it would drain every DMA in flight). LDS reads of the waiting wave must have been consumed before (they feed MFMAs).
+__device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
+// K == 256 (the batch contraction of the headline configuration): the two 128-k halves of the images are two stages, X and Y,
+// and the block's NEXT weight-gradient tile (the dealing loop knows it) is streamed in behind the running one - X' while Y is
+// being multiplied, Y' under the stores: [wait X | mul X | issue X' | wait Y | mul Y | store | issue Y'] - so a tile costs its
+// 128 MFMAs per wave instead of [load 128 KB out of the Infinity Cache, then multiply] (r03: 9.7 us per tile, 3.7 of them
+// MFMA). Every wave issues 8 DMA instructions per half, so "all but my youngest 8" is the wait for the older half whatever
+// stores lie in between. `pre` == WG64_INFLIGHT: the previous tile left this tile's halves in flight; returns the same for the next.
+constexpr int WG64_INFLIGHT = -1;
+__device__ __forceinline__ int wg64_tile(const fl_pjob& jb, int rt, int ct, const ProgIO& io, float* smem, const bool wt, const int pre,
+                                         const jobwords_t njw, const bool has_next, const int nrt, const int nct) {
   const int w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), w = w8 & 3;  // 8 waves load, waves 0-3 compute
   const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
   const int wr = w >> 1, wc = w & 1;
@@ -428,6 +439,95 @@ __device__ __forceinline__ void wg64_tile(const fl_pjob& jb, int rt, int ct, con
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const bool colsum = (jb.flags & FL_PG_COLSUM) != 0 && ct == 0 && wc == 0;
   float cs = 0.f;
+  if (K == 256) {
+    bool nx = false;
+    const float* nA0 = A0;
+    const float* nW0 = W0;
+    int nlda = lda, nldw = ldw;
+    if (has_next) {
+      const int nfl = ldsi(njw, FL_JW(flags));
+      nx = ldsi(njw, FL_JW(kind)) == FL_PJOB_GEMM && (nfl & (FL_PG_T64 | FL_PG_TA | FL_PG_TW)) == (FL_PG_T64 | FL_PG_TA | FL_PG_TW) &&
+           ldsi(njw, FL_JW(K)) == 256;
+      if (nx) {
+        nA0 = rp(ldsp(njw, FL_JW(A)), io) + nrt * 64 + (lane & 15) * 4;
+        nW0 = rp(ldsp(njw, FL_JW(W)), io) + nct * 64 + (lane & 15) * 4;
+        nlda = ldsi(njw, FL_JW(lda));
+        nldw = ldsi(njw, FL_JW(ldw));
+      }
+    }
+    // wave w8 moves rows [16 w8, 16 w8 + 16) of a half of both images: 4 x (4 rows x 256 B) each
+    auto issue = [&](const float* Ab, const float* Wb, int lda_, int ldw_, int half) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row4 = half * 128 + (w8 * 4 + q) * 4, kr = row4 + (lane >> 4);
+        __builtin_amdgcn_global_load_lds((gptr_t)(Ab + (size_t)__umul24((unsigned)kr, (unsigned)lda_)), (lptr_t)(imgA + row4 * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(Wb + (size_t)__umul24((unsigned)kr, (unsigned)ldw_)), (lptr_t)(imgW + row4 * 64), 16, 0, 0);
+      }
+    };
+    // a half = 64 MFMA steps (k pairs); the fragments of the next 16 steps are read before the MFMAs of the running 16 are issued
+    // (read-then-multiply in one piece cost 6.7 us per tile for 3.7 us of MFMAs)
+    auto mul = [&](int half) {
+      if (!compute) return;
+      const float* pa = imgA + (half * 128 + lh) * 64 + 32 * wr + lr;
+      const float* pw = imgW + (half * 128 + lh) * 64 + 32 * wc + lr;
+      float fa[2][16], fw[2][16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        fa[0][j] = *(const lf1_t*)(pa + j * 128);
+        fw[0][j] = *(const lf1_t*)(pw + j * 128);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (b + 1 < 4) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            fa[(b + 1) & 1][j] = *(const lf1_t*)(pa + (16 * (b + 1) + j) * 128);
+            fw[(b + 1) & 1][j] = *(const lf1_t*)(pw + (16 * (b + 1) + j) * 128);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[b & 1][j], fw[b & 1][j], acc, 0, 0, 0);
+          cs += fa[b & 1][j];
+        }
+      }
+    };
+    FL_STAMP(4);
+    if (pre != WG64_INFLIGHT) {
+      issue(A0, W0, lda, ldw, 0);
+      issue(A0, W0, lda, ldw, 1);
+    }
+    FL_STAMP(7);
+    FL_STAMP(8);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // X (and whatever the previous tile stored) is done; Y may still fly
+    raw_barrier();
+    FL_STAMP(9);
+    mul(0);
+    raw_barrier();  // every wave has read X
+    if (nx) {
+      issue(nA0, nW0, nlda, nldw, 0);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    raw_barrier();  // Y has landed
+    mul(1);
+    raw_barrier();  // every wave has read Y
+    FL_STAMP(1);
+    float* C = wp(jb.C, io) + (long long)(rt * 64 + 32 * wr + 4 * lh) * jb.ldc + ct * 64 + 32 * wc + lr;
+    if (compute) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st1g(wt, C + (long long)((r & 3) + 8 * (r >> 2)) * jb.ldc, acc[r]);
+    }
+    if (colsum && compute) {
+      cs += __shfl_xor(cs, 32, 64);
+      const float gmul = jb.gate ? 1.f + fl::sigmoid_acc(ld1g(rp(jb.gate, io))) : 1.f;
+      if (lh == 0) st1g(wt, wp(jb.aux[0], io) + rt * 64 + 32 * wr + lr, jb.alpha * gmul * cs);
+    }
+    if (nx) issue(nA0, nW0, nlda, nldw, 1);
+    FL_STAMP(10);
+    return nx ? WG64_INFLIGHT : (pre == WG64_INFLIGHT ? 0 : pre);
+  }
   const float e_gate = jb.gate ? ld1g(rp(jb.gate, io)) : 0.f;
   for (int kk = 0; kk < K; kk += 256) {
     const int kv = K - kk < 256 ? K - kk : 256;
@@ -485,6 +585,7 @@ __device__ __forceinline__ void wg64_tile(const fl_pjob& jb, int rt, int ct, con
     if (lh == 0) st1g(wt, wp(jb.aux[0], io) + rt * 64 + 32 * wr + lr, jb.alpha * gmul * cs);
   }
   __syncthreads();  // the images are the next tile's stage
+  return pre == WG64_INFLIGHT ? 0 : pre;
 }
 
 // ---------------------------------------------------------------------------------------------- LDS-DMA GEMM tile
@@ -504,9 +605,6 @@ __device__ __forceinline__ void wait_vm(int n) {
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
-// the workgroup barrier WITHOUT the memory fence of __syncthreads() (hipcc puts s_waitcnt vmcnt(0) lgkmcnt(0) in front of that
-// one: it would drain every DMA in flight). LDS reads of the waiting wave must have been consumed before (they feed MFMAs).
-__device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
 
 // Operand streams of a FL_PG_DMA job: up to three concatenated-K segments per operand, walked in 128-wide chunks.
 // (Local scalars, copied out of the descriptor BEFORE any select: a struct or array whose members are picked by a
@@ -1584,8 +1682,10 @@ __device__ __forceinline__ void tile_coords(const Deal& d, const Win& w, bool lo
 __device__ __forceinline__ bool prefetchable(const Win& w, const Cur& c) { return c.j >= 0 && (win_tb(w, c.j) & JI_PF) != 0; }
 
 // returns the prefetch DMA instructions the wave left in flight for the block's next tile
+// (tjw, tnext, trt, tk): the tile this block runs next IN THIS PHASE, if any (the weight-gradient tiles stream it in behind themselves)
 __device__ __forceinline__ int run_tile(const jobwords_t jw, int rt, int k, const ProgIO& io, float* smem, const bool wt, const int pre,
-                                        const jobwords_t& njw, const bool prefetch, const int pf_ct) {
+                                        const jobwords_t& njw, const bool prefetch, const int pf_ct, const jobwords_t& tjw,
+                                        const bool tnext, const int trt, const int tk) {
   const int kind = ldsi(jw, FL_JW(kind)), flags = ldsi(jw, FL_JW(flags));
   if (kind == FL_PJOB_GEMM && (flags & FL_PG_DMA)) {
     if (flags & FL_PG_TW) return gemm_dma_tile<true>(jw, rt, k, io, smem, wt, pre, njw, prefetch, pf_ct);
@@ -1601,8 +1701,8 @@ __device__ __forceinline__ int run_tile(const jobwords_t jw, int rt, int k, cons
         case 0: gemm_tile<false, false>(jb, rt, k, io, smem, wt); break;
         case FL_PG_TW: gemm_tile<false, true>(jb, rt, k, io, smem, wt); break;
         case FL_PG_TA | FL_PG_TW:
-          if (flags & FL_PG_T64) wg64_tile(jb, rt, k, io, smem, wt);
-          else gemm_tile<true, true>(jb, rt, k, io, smem, wt);
+          if (flags & FL_PG_T64) return wg64_tile(jb, rt, k, io, smem, wt, pre, tjw, tnext, trt, tk);
+          gemm_tile<true, true>(jb, rt, k, io, smem, wt);
           break;
         default: break;  // TA alone: rejected by fl_program_job_tiles
       }
@@ -1772,7 +1872,7 @@ __global__ __launch_bounds__(512, 1) void program_kernel(const fl_pphase* __rest
         }
       }
       FL_STAMP(3);  // the next tile(s) are dealt and their descriptors requested
-      pre = run_tile(jw, rt, k, io, smem, wt, pre, jwp, pw, pk);
+      pre = run_tile(jw, rt, k, io, smem, wt, pre, jwp, pw, pk, jwn, nxt.j >= 0, nrt, nk);
       have = nxt.j >= 0;
       if (pf_ok) {
         jw = jwn;
