@@ -245,9 +245,12 @@ int fl_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
 /* Fused multi-head self-attention over the HW tokens of a feature map (UNetAttentionBlock, v2:446-457): one launch for
  * softmax(scale * Q K^T) V of every (image, head), no (HW x HW) tensor in HBM. qkv (B,HW,3C): channel = which*C + head*d + i
  * (NHWC output of the 1x1 qkv conv); out (B,HW,C): channel = i*heads + head (the d-major merge of v2:456-457); P optional
- * (B,heads,HW,HW): the normalised weights, kept only when a backward will need them. QK^T and PV on v_mfma_f32_32x32x2_f32
- * (exact fp32); the score tile is built transposed so that the row softmax is in-lane arithmetic + one wave shuffle and the
- * accumulator tile feeds the PV MFMA as it stands. Needs HW % 32 == 0, C / heads <= 32. */
+ * (B,heads,HW,HW): the normalised weights, kept only when a backward will need them. Exact-fp32 MFMAs; the score tile is
+ * built transposed so that the row softmax is in-lane arithmetic + wave shuffles and the accumulator tile feeds the PV MFMA as
+ * it stands. Two kernels: ONE pass over the keys (online softmax, v_mfma_f32_16x16x4_f32, K / V^T staged in LDS per block, exp2
+ * on the transcendental pipe) when P == NULL, d = C / heads is a multiple of 4 up to 64, HW % 64 == 0 and qkv is 16-byte
+ * aligned; otherwise the two-pass kernel on v_mfma_f32_32x32x2_f32 (HW % 32 == 0, d <= 32). stats optional (B,heads,HW,2):
+ * (row max of scale*s, sum of exp) - what fl_attention_bwd (d <= 32) recomputes the weights from. */
 int fl_attention_fwd(const float* qkv, float* out, float* P, float* stats, int B, int HW, int C, int heads, float scale,
                      fl_stream_t stream);
 /* stats optional (B,heads,HW,2): per query the max of scale*s and the sum of exp - all the backward needs to recompute P.

@@ -107,6 +107,146 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const AttnArgs g) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------- forward, one pass
+// The same contraction in ONE pass over the keys (online softmax), on v_mfma_f32_16x16x4_f32 and with K / V staged in LDS once per
+// block (round 2's kernel above: two passes, every wave fetching its own K / V fragments from global memory, V^T padded to 32
+// rows - at d = 16 half of its P V MFMAs multiplied zeros - and the accurate expf: 0.377 ms = 14.5 % of the fp32 MFMA peak).
+//   * block = 512 threads = 8 waves x 32 queries of one (image, head); the keys go through LDS in chunks of 256: K as it lies
+//     ([key][DH]), V TRANSPOSED ([dim][256 + 4]) so that every MFMA operand below is one conflict-free ds_read_b128;
+//   * 16 x 16 tiles: S^T = K Q^T puts query lane & 15 in a lane and keys 4 (lane >> 4) + r in its four accumulator registers;
+//     register r - after exp - IS the B operand of the P V step that contracts keys {4 g + r}: no lane movement, no LDS, and
+//     V^T has exactly d rows (no padding work for d = 16). The contraction index of S is walked as dim = 16 jj + 4 g + e so that
+//     a lane's four steps read ONE float4 of K and of Q;
+//   * softmax per 64 keys: running max (two xor-shuffles among the 4 lanes of a query), p = exp2(s' - m') on the fast
+//     transcendental pipe with scale * log2(e) folded into Q, accumulators rescaled by exp2(m_old - m_new), the row sums kept
+//     per lane and added up once at the end. stats = (m' ln 2, l): what fl_attention_bwd recomputes P from.
+template <int DH>
+__global__ __launch_bounds__(512, (DH <= 32 ? 4 : 2)) void attention_fwd_onepass_kernel(const AttnArgs g) {
+  constexpr int KC = 256, NJ = DH / 16, PV = KC + 4;
+  constexpr int KT = DH <= 32 ? 4 : 2;  // key tiles (of 16) per softmax group: bounded by the fragment registers
+  typedef float f32x4a __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float at_smem[];
+  float* Ks = at_smem;
+  float* Vt = at_smem + KC * DH;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, g4 = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 256 + 32 * w;
+  const bool active = q0 < g.HW;  // wave-uniform; HW % 32 == 0: all 32 queries exist
+  const int C3 = 3 * g.C, d = g.d;
+  const float* base = g.qkv + (size_t)b * g.HW * C3 + h * d;
+  const float qs = g.scale * 1.4426950408889634f;
+
+  f32x4a qf[2][NJ];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int dim = 16 * jj + 4 * g4;
+      f32x4a v = {0.f, 0.f, 0.f, 0.f};
+      if (active && dim < d) v = *reinterpret_cast<const f32x4a*>(base + (size_t)(q0 + 16 * qt + ln) * C3 + dim);
+      qf[qt][jj] = v * qs;
+    }
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+  f32x4a o[2][NJ];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int mt = 0; mt < NJ; ++mt) o[qt][mt] = f32x4a{0.f, 0.f, 0.f, 0.f};
+
+  for (int kc = 0; kc < g.HW; kc += KC) {
+    const int nk = g.HW - kc < KC ? g.HW - kc : KC;
+    __syncthreads();  // the previous chunk has been consumed
+    for (int idx = tid; idx < nk * (DH / 4); idx += 512) {
+      const int key = idx / (DH / 4), c4 = idx - key * (DH / 4);
+      f32x4a kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (4 * c4 < d) {
+        const float* src = base + (size_t)(kc + key) * C3 + 4 * c4;
+        kv = *reinterpret_cast<const f32x4a*>(src + g.C);
+        vv = *reinterpret_cast<const f32x4a*>(src + 2 * g.C);
+      }
+      *reinterpret_cast<f32x4a*>(Ks + key * DH + 4 * c4) = kv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Vt[(4 * c4 + e) * PV + key] = vv[e];
+    }
+    __syncthreads();
+    if (!active) continue;
+    for (int kg = 0; kg < nk; kg += 16 * KT) {
+      f32x4a kf[KT][NJ], vf[KT][NJ];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+          kf[kt][jj] = *reinterpret_cast<const f32x4a*>(Ks + (kg + 16 * kt + ln) * DH + 16 * jj + 4 * g4);
+          vf[kt][jj] = *reinterpret_cast<const f32x4a*>(Vt + (16 * jj + ln) * PV + kg + 16 * kt + 4 * g4);
+        }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x4a sc[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          sc[kt] = f32x4a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][jj][e], qf[qt][jj][e], sc[kt], 0, 0, 0);
+        }
+        float mx = sc[0][0];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m[qt], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);
+        m[qt] = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sc[kt][r] = __builtin_amdgcn_exp2f(sc[kt][r] - mn);
+            ps += sc[kt][r];
+          }
+        l[qt] = l[qt] * alpha + ps;
+#pragma unroll
+        for (int mt = 0; mt < NJ; ++mt) o[qt][mt] = o[qt][mt] * alpha;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < NJ; ++mt) o[qt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][mt][r], sc[kt][r], o[qt][mt], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float lt = l[qt];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const float inv = 1.0f / lt;
+    const int q = q0 + 16 * qt + ln;
+    if (g.stats && g4 == 0) {
+      float* st = g.stats + (((size_t)b * g.nh + h) * g.HW + q) * 2;
+      st[0] = m[qt] * 0.6931471805599453f;
+      st[1] = lt;
+    }
+    // O^T tile: row i = 16 mt + 4 g4 + r, column = query ln -> out[b, q, i * heads + h]
+    float* Oq = g.out + ((size_t)b * g.HW + q) * g.C + h;
+#pragma unroll
+    for (int mt = 0; mt < NJ; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * mt + 4 * g4 + r;
+        if (i < d) Oq[(size_t)i * g.nh] = o[qt][mt][r] * inv;
+      }
+  }
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------- backward
 // dQ, dK, dV of the attention core in two launches, no (HW x HW) tensor in HBM and no atomics: the probabilities are
 // recomputed from Q, K and the forward's row statistics (m = max of scale*s, l = sum of exp).
@@ -263,12 +403,30 @@ int fl_attention_fwd(const float* qkv, float* out, float* P, float* stats, int B
   FL_REQUIRE(qkv && out && B >= 0 && HW > 0 && C > 0 && heads > 0, "fl_attention_fwd: bad arguments");
   FL_REQUIRE(C % heads == 0 && HW % 32 == 0, "fl_attention_fwd: C %% heads == 0 and HW %% 32 == 0 required (C=%d heads=%d HW=%d)", C, heads, HW);
   const int d = C / heads;
-  FL_REQUIRE(d <= 32, "fl_attention_fwd: head dim %d > 32", d);
+  // one-pass kernel: no P output, head dim a multiple of 4 up to 64, key groups of 64; anything else: the two-pass kernel (d <= 32)
+  const bool onepass = !P && d % 4 == 0 && d <= 64 && HW % 64 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0;
+  FL_REQUIRE(onepass || d <= 32, "fl_attention_fwd: head dim %d > 32 needs HW %% 64 == 0, d %% 4 == 0, d <= 64 and no P output", d);
   if (B == 0) return FL_OK;
   AttnArgs g;
   g.qkv = qkv; g.out = out; g.P = P; g.stats = stats; g.B = B; g.HW = HW; g.C = C; g.nh = heads; g.d = d; g.scale = scale;
-  dim3 grid((unsigned)fl::cdiv(HW, 128), (unsigned)heads, (unsigned)B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (onepass) {
+    dim3 grid1((unsigned)fl::cdiv(HW, 256), (unsigned)heads, (unsigned)B);
+    const int DH = d <= 16 ? 16 : (d <= 32 ? 32 : 64);
+    const size_t lds = (size_t)(256 * DH + DH * 260) * sizeof(float);
+    if (DH == 16) hipLaunchKernelGGL(attention_fwd_onepass_kernel<16>, grid1, dim3(512), lds, s, g);
+    else if (DH == 32) {
+      static bool attr = (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_onepass_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+      (void)attr;
+      hipLaunchKernelGGL(attention_fwd_onepass_kernel<32>, grid1, dim3(512), lds, s, g);
+    } else {
+      static bool attr = (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_onepass_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+      (void)attr;
+      hipLaunchKernelGGL(attention_fwd_onepass_kernel<64>, grid1, dim3(512), lds, s, g);
+    }
+    return fl::check_launch("attention_fwd_onepass_kernel");
+  }
+  dim3 grid((unsigned)fl::cdiv(HW, 128), (unsigned)heads, (unsigned)B);
   if (d <= 16) hipLaunchKernelGGL(attention_fwd_kernel<16>, grid, dim3(256), 0, s, g);
   else hipLaunchKernelGGL(attention_fwd_kernel<32>, grid, dim3(256), 0, s, g);
   return fl::check_launch("attention_fwd_kernel");

@@ -797,3 +797,31 @@ def test_fused_attention_backward_vs_autograd(dev, shape):
     dq = ops.attention_bwd(qd, merged, dmerged.to(dev), st, nh, scale)
     for which, name in enumerate(("dQ", "dK", "dV")):
         close(dq[..., which * C:(which + 1) * C], q64.grad[..., which * C:(which + 1) * C], 3e-5)   # dQ, dK, dV
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64, 4), (3, 16, 16, 128, 8), (2, 16, 16, 128, 4), (1, 32, 32, 64, 2), (2, 8, 8, 128, 2),
+                                   (1, 16, 16, 96, 4), (1, 8, 4, 96, 4), (1, 16, 8, 192, 4)])
+def test_attention_forward_onepass_vs_fp64(dev, shape):
+    """fl_attention_fwd: the one-pass kernel (online softmax, 16x16x4 fp32 MFMAs, K / V^T in LDS; head dims 16, 16, 32, 32, 64, 24,
+    and 1024 keys = four LDS chunks) and the two-pass kernel it falls back to (HW = 32; P output) against torch fp64 softmax(scale
+    Q K^T) V with the d-major head merge of v2:456-457: 2e-5 of the output's max (exp2 on the transcendental pipe: ~1 ulp per
+    weight); the row statistics reproduce the weights: exp(scale s - m) / l."""
+    B, H, W, C, nh = shape
+    HW, d = H * W, C // nh
+    g = torch.Generator().manual_seed(B * 100 + C + HW)
+    qkv = torch.randn(B, H, W, 3 * C, generator=g) * 1.5
+    scale = float(d) ** -0.5
+    t = qkv.double().reshape(B, HW, 3, nh, d).permute(2, 0, 3, 1, 4)               # (3, B, nh, HW, d)
+    logits = scale * t[0] @ t[1].transpose(-1, -2)
+    P = torch.softmax(logits, dim=-1)
+    ref = (P @ t[2]).permute(0, 2, 3, 1).reshape(B, H, W, C)                        # channel = i * heads + head
+    qd = qkv.to(dev)
+    merged, st = ops.attention_fwd(qd, nh, scale, want_stats=True)
+    close(merged, ref, 2e-5)
+    st = st.cpu().double()
+    Pst = torch.exp(logits - st[..., 0:1]) / st[..., 1:2]
+    assert (Pst - P).abs().max().item() <= 2e-6
+    if d <= 32:   # the P output takes the two-pass kernel: same numbers
+        merged2, P2 = ops.attention_fwd(qd, nh, scale, want_p=True)
+        close(merged2, ref, 2e-5)
+        assert (P2.cpu().double() - P).abs().max().item() <= 2e-6
