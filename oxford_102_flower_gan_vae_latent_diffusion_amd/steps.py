@@ -288,9 +288,13 @@ class DDPMTrainer:
         with torch.cuda.graph(self.g1):
             z = self.encode(self.static_data)
             self.fwd_bwd(z, self.static_labels)
-        self.g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g2, pool=self.g1.pool()):
-            self.update()
+            if self.world == 1:   # nothing sits between the gradients and the update: one graph launch per step instead of two
+                self.update()
+        self.g2 = None
+        if self.world > 1:
+            self.g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+                self.update()
         self.graph = True
 
     def check_programs(self):
@@ -312,8 +316,9 @@ class DDPMTrainer:
 
     def replay(self):
         self.g1.replay()
-        self.allreduce()
-        self.g2.replay()
+        if self.g2 is not None:
+            self.allreduce()
+            self.g2.replay()
         self._replayed()
         return self.loss
 
