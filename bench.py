@@ -26,12 +26,17 @@ MFMA16_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense 16-bit (bf16 / f16)
 BF16X3_PRODUCTS = 6             # bf16 MFMAs per fp32 product in the "split" GEMM math of gemm.hip (flowers_hip.h)
 F16X2_PRODUCTS = 3              # f16 MFMAs per fp32 product in the f16x2 conv kernels (conv_h2.hip)
 # HBM-side bytes per launch of the f16x2 conv kernels at B=256, averaged over a kernel's launches in one step: rocprofv3
-# PMC passes (FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), profiles/r02_conv_h2_pmc.md. None = not measured.
+# PMC passes (FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes), profiles/r03_conv_h2_pmc.md (the round-3 kernels;
+# r02_conv_h2_pmc.md: the round-2 ones). None = not measured.
 PMC_TRAFFIC = {"h2_3x3": None, "h2_4x4": None}
-try:
-    PMC_TRAFFIC.update(json.load(open(os.path.join(ROOT, "profiles", "r02_conv_h2_pmc.json"))))
-except (OSError, ValueError):
-    pass
+PMC_SOURCE = None
+for _tag in ("r03", "r02"):
+    try:
+        PMC_TRAFFIC.update(json.load(open(os.path.join(ROOT, "profiles", "%s_conv_h2_pmc.json" % _tag))))
+        PMC_SOURCE = "profiles/%s_conv_h2_pmc.md" % _tag
+        break
+    except (OSError, ValueError):
+        pass
 # algorithmic GFLOP per image (forward MACs x 2)
 GFLOP_PER_IMAGE_STEP = 2.748     # config 3/4: frozen encoder fwd + denoiser fwd+bwd (3 x fwd)
 GFLOP_PER_IMAGE_VAEGAN = 22.75   # config 2
@@ -627,7 +632,7 @@ def main():
                 "issued_16bit_mfma_tflops": r["tflops"] * r["pp"] if r["pp"] else None,
                 "library_bf16_gemm_8192_tflops": library_gemm_tflops(dev),
                 "traffic": PMC_TRAFFIC.get(dom) if B == 256 else None,
-                "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/r02_conv_h2_pmc.md" if PMC_TRAFFIC.get(dom) else None,
+                "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), %s" % PMC_SOURCE if PMC_TRAFFIC.get(dom) else None,
                 "algorithmic_bytes_per_launch": r["bytes_per_launch"],
                 "avg_launch_ms": r["avg_ms"],
                 "algorithmic_gflop_per_launch": r["flop_per_launch"] / 1e9,

@@ -1,8 +1,8 @@
 """HBM-side traffic per launch of the f16x2 conv kernels from the two rocprofv3 PMC databases made with tools/conv_pmc.py
 (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes). FETCH_SIZE is in KB and counts a wide
 coalesced streaming read at half its bytes on gfx950 -> doubled; the streaming calibration kernel in the same run
-(fl_affine_act, 134 MB read + 134 MB written) shows the correction. Writes profiles/r02_conv_h2_pmc.{md,json}.
-Usage: python tools/pmc_summary.py FETCH_DB WRITE_DB"""
+(fl_affine_act, 134 MB read + 134 MB written) shows the correction. Writes profiles/<TAG>_conv_h2_pmc.{md,json}.
+Usage: python tools/pmc_summary.py FETCH_DB WRITE_DB [TAG, default r03]"""
 import json
 import os
 import re
@@ -31,6 +31,7 @@ def last_rep(rs):
 
 def main():
     fdb, wdb = sys.argv[1], sys.argv[2]
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
     f, w = last_rep(rows(fdb, "FETCH_SIZE")), last_rep(rows(wdb, "WRITE_SIZE"))
     names = ["calibration: affine_act 256x32x32x128"] + ["down1 4x4s2", "res1.conv1 3x3", "res1.conv2 3x3", "down2 4x4s2", "res2.conv1 3x3",
                                                         "res2.conv2 3x3", "down3 4x4s2", "res3.conv1 3x3", "res3.conv2 3x3"]
@@ -42,7 +43,7 @@ def main():
     for (C, H) in ((128, 32), (256, 16), (512, 8)):
         alg.append(4.0 * B * ((2 * H) ** 2 * (C // 2) + H * H * C) + 4.0 * C * 16 * (C // 2))
         alg += [4.0 * B * (2 * H * H * C) + 4.0 * C * 9 * C] * 2
-    lines = ["# HBM-side traffic of the f16x2 conv kernels (round 2)", "",
+    lines = ["# HBM-side traffic of the f16x2 conv kernels (%s)" % tag, "",
              "rocprofv3 `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, `--kernel-trace` only) over `tools/conv_pmc.py`: one launch of",
              "each frozen-encoder conv at B = 256 exactly as the step launches it, third repetition. FETCH_SIZE (KB) is doubled (gfx950 counts a",
              "128-B request of a wide coalesced read as 64 B, MI355X_MICROARCH.md section HBM); the calibration row - a streaming kernel that reads",
@@ -59,9 +60,9 @@ def main():
             out["h2_4x4"].append(tot)
     res = {k: sum(v) / len(v) for k, v in out.items()}
     lines += ["", "Average per launch: conv3x3_h2_kernel %.1f MB (6 launches), conv4x4s2_h2_kernel %.1f MB (3 launches) - `roofline.traffic` in the"
-              % (res["h2_3x3"] / 1e6, res["h2_4x4"] / 1e6), "bench line (read from profiles/r02_conv_h2_pmc.json)."]
-    open(os.path.join(ROOT, "profiles", "r02_conv_h2_pmc.md"), "w").write("\n".join(lines) + "\n")
-    json.dump(res, open(os.path.join(ROOT, "profiles", "r02_conv_h2_pmc.json"), "w"))
+              % (res["h2_3x3"] / 1e6, res["h2_4x4"] / 1e6), "bench line (read from profiles/%s_conv_h2_pmc.json)." % tag]
+    open(os.path.join(ROOT, "profiles", "%s_conv_h2_pmc.md" % tag), "w").write("\n".join(lines) + "\n")
+    json.dump(res, open(os.path.join(ROOT, "profiles", "%s_conv_h2_pmc.json" % tag), "w"))
     print("\n".join(lines))
 
 
