@@ -127,7 +127,10 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
  * products exact, fp32 accumulation): error vs fp64 0.5-1.7e-6 of the output's max for K = 1024..4608 (2-4x the native fp32
  * MFMA kernel's accumulation error, the class of the bf16x3 scheme) at half the matrix instructions of the bf16x3 scheme. fl_pack_weight_f16x2 scales (per tensor, amax -> [2^14,2^15)), splits
  * and lays out the packed weight [Cout][kh*kw*Cin] once (fl_pack_weight_f16x2_bytes(N,K) = 256 + 4*N*K bytes;
- * layout 0 for the 3x3 kernel, 1 for the 4x4 one, whose 16-wide k groups pair two taps x 8 channels).
+ * layout 1 for the 4x4 kernel, whose 16-wide k groups pair two taps x 8 channels; for the 3x3 kernel layout 2 when Cin % 64 == 0
+ * (32-wide k groups pairing two taps x 16 channels for v_mfma_f32_16x16x32_f16: the shape that sustains the higher clock on
+ * LDS-fed random operands, profiles/r03_mfma_shape_probe.txt) and layout 0 otherwise - fl_conv2d_fwd_f16x2 picks its kernel by
+ * the same rule, fl_conv2d_f16x2_weight_layout(kh, Cin) returns it).
  * Activations are scaled by 2^x_exp, or - when x_amax != NULL - by the power of two that maps *x_amax (a device float
  * >= max|x|, kept by the kernel that produced x) into [2^14,2^15). |x| 2^e >= 65520 yields NaN outputs (loud).
  * Needs Cout % 128 == 0 and: 3x3 H == W in {8,16,32}, Cin % 32 == 0, B*H*W % 128 == 0 (256-pixel tiles, one 8-wave block per
@@ -138,6 +141,7 @@ int fl_conv2d_fwd_presplit(const float* x, const void* wsplit, const float* bias
  * producer's LayerNorm2d-apply + Swish (v2:163-164, v2:193-194) fused into the halo staging, so that pass never
  * touches HBM; x_amax / x_exp then bound the transformed values. */
 size_t fl_pack_weight_f16x2_bytes(int N, int K);
+int fl_conv2d_f16x2_weight_layout(int kh, int Cin);
 int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, fl_stream_t stream);
 int fl_conv2d_fwd_f16x2_applicable(const float* x, int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 /* nn.Linear forward with a long reduction in f16x2 split math (the frozen encoder's heads, v2:210-221: K = 32768): y = x W^T +

@@ -140,6 +140,63 @@ __device__ __forceinline__ void h2_stats_tail(const H2Args& g, const float (&st1
   }
 }
 
+// the same tail for the 16 x 16 MFMA layout of conv3x3_h2p_kernel: st1 / st2 = this lane's sums over its 16 of the wave's 64 rows
+// for four 16-column tiles; lanes kg == 0 end up with the wave's column sums
+__device__ __forceinline__ void h2p_stats_tail(const H2Args& g, const float (&st1)[4], const float (&st2)[4], int tile_m0, int tile_n0,
+                                               int wr, int wc, int l16, int kg, char* smem) {
+  if (!g.stats && !g.fin) return;
+  float a[4], b[4];
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    a[tn] = st1[tn] + __shfl_xor(st1[tn], 16, 64);
+    b[tn] = st2[tn] + __shfl_xor(st2[tn], 16, 64);
+    a[tn] += __shfl_xor(a[tn], 32, 64);
+    b[tn] += __shfl_xor(b[tn], 32, 64);
+  }
+  if (g.fin == 1) {
+    const int img = (tile_m0 + wr * 64) / 64;
+    if (kg == 0) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) h2_finish_stats(g, img, tile_n0 + wc * 64 + tn * 16 + l16, (double)a[tn], (double)b[tn], 64);
+    }
+  } else if (g.fin == 2) {
+    float* ex = reinterpret_cast<float*>(smem);  // [slab 4][sum | sum of squares][128 columns]
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        ex[(wr * 2) * 128 + wc * 64 + tn * 16 + l16] = a[tn];
+        ex[(wr * 2 + 1) * 128 + wc * 64 + tn * 16 + l16] = b[tn];
+      }
+    }
+    __syncthreads();
+    if (wr == 0 && kg == 0) {
+      const int img = tile_m0 / 256;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int c = wc * 64 + tn * 16 + l16;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+          s1 += (double)ex[(sl * 2) * 128 + c];
+          s2 += (double)ex[(sl * 2 + 1) * 128 + c];
+        }
+        h2_finish_stats(g, img, tile_n0 + c, s1, s2, 256);
+      }
+    }
+  } else {
+    const int grp = (tile_m0 + wr * 64) / 64;
+    if (kg == 0) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int col = tile_n0 + wc * 64 + tn * 16 + l16;
+        g.stats[((size_t)grp * 2) * g.Cout + col] = a[tn];
+        g.stats[((size_t)grp * 2 + 1) * g.Cout + col] = b[tn];
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ int scale_exp_from_amax(unsigned bits) {
   const int E = (int)((bits >> 23) & 0xffu);
   int e = E ? 141 - E : 0;  // amax * 2^e in [2^14, 2^15)
@@ -540,6 +597,359 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
   // fused LayerNorm2d statistics: this wave's 64 rows lie in one image (H*W % 64 == 0): one slab of (sum y, sum y^2) - or,
   // where the tile holds whole images, the finished scale / shift
   h2_stats_tail(g, st1, st2, tile_m0, tile_n0, wr, wc, li, lh, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same 3x3 convolution on v_mfma_f32_16x16x32_f16 ("pair" kernel; Cin % 64 == 0, weights packed in layout 2).
+// tools/mfma_shape_probe.hip: with RANDOM operands coming out of LDS the chip sustains 1.43 PFLOP/s of issued f16 MFMA in the
+// 32x32x16 shape and 1.60 in the 16x16x32 shape (2.15 / 1.99 on zero operands: the difference is the clock the chip holds under
+// load, profiles/r03_mfma_shape_probe.txt) - the 32x32x16 kernel above runs at 1.22, i.e. 85 % of ITS ceiling.
+// A 32-wide k step pairs two (tap, 16-channel chunk) groups: lanes 0-31 (k slots 0-15) take the even member, lanes 32-63 the odd
+// one - a per-lane byte offset into the same staged planes, whose layout does not change. Over two chunks the 18 taps make 9
+// pairs (pair 4 = tap 8 of the even chunk + tap 0 of the odd one: both buffers live), so the loop body is one 2-chunk period.
+// Wave tile 64 x 64 = 4 x 4 MFMA tiles, 48 MFMAs (16 cycles each) per pair and ONE barrier per pair (half the barriers).
+// Registers: a full double buffer of the fragments (2 x 64 VGPRs) does not fit, so the sets retire piecewise. Piece order
+// (a_l b_h), (a_h b_l), (a_h b_h); a_l', b_h' (second buffer), b_l' of the NEXT pair are read as their registers fall free,
+// a_h is read INSIDE its pair (under piece 1) - which moves a chunk buffer's last read one pair later: the odd chunk is
+// converted in pairs 1-2 (halo loads issued in pair 7, waited for behind pair 0), the even one in pairs 6-7 (loads in pair 3,
+// waited for behind pair 5). Weight ring: 3 slots of 16 KB (one pair of the block's 128 columns); a pair's fragments are all read
+// during the pair before it, so pair p refills its own slot with pair p + 3.
+template <int W, int BM_>
+struct H2PGeom {
+  static constexpr int BM = BM_, BN = 128;
+  static constexpr int R = BM / W, RI = R < W ? R : W, NI = R / RI, HR = RI + 2, HC = W + 2;
+  static constexpr int PXB = 48;
+  // W = 8: the conflict-free pitch (640) does not leave room for the 48 KB ring next to 16 KB of pre-op coefficients (Cin = 512):
+  // 480 costs a 2-way conflict on two of a read's sixteen 16-byte slots
+  static constexpr int RPB = W == 32 ? HC * PXB : (W == 16 ? 1024 : 480);
+  static constexpr int PLANE_B = NI * HR * RPB, ABUF_B = 2 * PLANE_B;
+  static constexpr int NS = 3, SLOT_B = 16384, BOFF = 2 * ABUF_B;
+  static constexpr int LDS_B = BOFF + NS * SLOT_B;
+  static constexpr int NT = 2 * BM, NWV = NT / 64, PPW = 16 / NWV;  // 1-KB weight-DMA pieces per wave and pair
+  static constexpr int P = NI * HR * HC, ITEMS = P * 4, NST = (ITEMS + NT - 1) / NT;
+  static_assert(RPB >= HC * PXB, "row pitch");
+  static_assert(LDS_B + 2 * NI * 512 * 4 <= 160 * 1024, "LDS");
+};
+// staging schedule of the pair kernel: nstep element steps over ngap MFMA gaps starting at gap 1
+constexpr int h2p_step_pos(int q, int nstep, int ngap) { return 1 + (q * (ngap - 1)) / nstep; }
+constexpr int h2p_step_at(int G, int nstep, int ngap) {
+  for (int q = 0; q < nstep; ++q)
+    if (h2p_step_pos(q, nstep, ngap) == G) return q;
+  return -1;
+}
+constexpr int h2p_ssload_pos(int j, int nst, int ngap) { return 48 * (h2p_step_pos(4 * j, 4 * nst, ngap) / 48) - 1; }
+
+template <int W, int PRE, int BM_ = 256>
+__global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2p_kernel(const H2Args g) {
+  using G = H2PGeom<W, BM_>;
+  constexpr int PPW = G::PPW;
+  constexpr int BM = G::BM, BN = G::BN, RI = G::RI, NI = G::NI, HR = G::HR, HC = G::HC, PXB = G::PXB, RPB = G::RPB;
+  constexpr int PLANE_B = G::PLANE_B, ABUF_B = G::ABUF_B, BOFF = G::BOFF, SLOT_B = G::SLOT_B;
+  constexpr int ITEMS = G::ITEMS, NT = G::NT, NST = G::NST;
+  static_assert(NST >= 3 && NST <= 5, "staging passes");
+  constexpr int NGAP = 88;  // gaps of a conversion window: a whole pair + the next one up to the point where new halo loads go out
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l16 = lane & 15, kg = lane >> 4;
+
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile_m0 = (tile / g.tiles_n) * BM;
+  const int tile_n0 = (tile % g.tiles_n) * BN;
+  const int img0 = tile_m0 / (W * W);
+  const int oy0 = (tile_m0 - img0 * (W * W)) / W;
+  const int Cin = g.Cin, nC = Cin >> 4;  // 16-channel chunks; nC % 4 == 0
+
+  const int ea = g.a_amax ? scale_exp_from_amax(*g.a_amax) : g.a_exp;
+  const float sa = __uint_as_float((unsigned)(ea + 127) << 23);
+  const float out_scale = reinterpret_cast<const float*>(g.wpack)[1] * __uint_as_float((unsigned)(127 - ea) << 23);
+
+  // ---- staging descriptors (as in conv3x3_h2_kernel)
+  int goff[NST], sdst[NST], ssoff[NST];
+  unsigned vmask = 0u;
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const int i = tid + NT * j;
+    const int pix = i >> 2, c4 = i & 3;
+    const int nl = pix / (HR * HC), rem = pix - nl * (HR * HC);
+    const int hy = rem / HC, hx = rem - hy * HC;
+    const int iy = oy0 - 1 + hy, ix = hx - 1;
+    const bool ok = (i < ITEMS) && ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
+    goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
+    sdst[j] = (i < ITEMS) ? (nl * HR + hy) * RPB + hx * PXB + c4 * 8 : 32;
+    ssoff[j] = (nl < NI ? nl : 0) * Cin + c4 * 4;
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+  float* ss = reinterpret_cast<float*>(smem + G::LDS_B);
+  if constexpr (PRE) {
+    for (int i = tid; i < NI * Cin; i += NT) {
+      const int nl = i / Cin, ch = i - nl * Cin;
+      ss[i] = g.pre_scale[(size_t)(img0 + nl) * Cin + ch];
+      ss[NI * Cin + i] = g.pre_shift[(size_t)(img0 + nl) * Cin + ch];
+    }
+    __syncthreads();
+  }
+
+  f32x4v stg[NST];
+  auto stage_load = [&](int c) {
+    const float* xc = g.x + c * 16;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const float* p = xc + goff[j];
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg[j]) : "v"(p) : "memory");
+    }
+  };
+#define FL_STAGE_WAIT(N)                                                                                                      \
+  do {                                                                                                                        \
+    if constexpr (NST == 3)                                                                                                   \
+      asm volatile("s_waitcnt vmcnt(%3)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]) : "i"(N) : "memory");                      \
+    else if constexpr (NST == 4)                                                                                              \
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[NST > 3 ? 3 : 0]) : "i"(N) : "memory"); \
+    else                                                                                                                      \
+      asm volatile("s_waitcnt vmcnt(%5)"                                                                                      \
+                   : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[NST > 3 ? 3 : 0]), "+v"(stg[NST > 4 ? 4 : 0])           \
+                   : "i"(N) : "memory");                                                                                      \
+  } while (0)
+  auto stage_item = [&](auto jc, int buf, int c) {  // prologue: one whole item
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < NST) {
+      char* dst = smem + buf * ABUF_B;
+      const bool ok = (vmask >> j) & 1u;
+      f32x4v v = stg[j];
+      if constexpr (PRE) {
+        const f32x4v sc = *reinterpret_cast<const f32x4v*>(ss + ssoff[j] + c * 16);
+        const f32x4v sh = *reinterpret_cast<const f32x4v*>(ss + NI * Cin + ssoff[j] + c * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = swish_fast(v[e] * sc[e] + sh[e]);
+      }
+      f16x4_t h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float X = ok ? v[e] * sa : 0.f;
+        const _Float16 hh = (_Float16)X;
+        h[e] = hh;
+        l[e] = (_Float16)(X - (float)hh);
+      }
+      *reinterpret_cast<f16x4_t*>(dst + sdst[j]) = h;
+      *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = l;
+    }
+  };
+  // main-loop staging: the chunk's 4 NST element steps dealt over the NGAP MFMA gaps of a conversion window (gap G = 48 * (pair
+  // inside the window) + gap inside the pair); an item's coefficients are read in the last gap of the pair before its first element
+  f32x4v ssc[NST], ssh[NST];
+  f16x4_t sth[NST], stl[NST];
+  auto stage_slot = [&](auto gc, int buf, int c) {
+    constexpr int G_ = decltype(gc)::value;
+    if constexpr (G_ >= -1 && G_ < NGAP) {
+      constexpr int q = G_ >= 0 ? h2p_step_at(G_, 4 * NST, NGAP) : -1;
+      if constexpr (PRE) {
+#define FL_SSLOAD(jl)                                                                                                         \
+        if constexpr (jl < NST && h2p_ssload_pos(jl < NST ? jl : 0, NST, NGAP) == G_) {                                        \
+          ssc[jl < NST ? jl : 0] = *reinterpret_cast<const f32x4v*>(ss + ssoff[jl < NST ? jl : 0] + c * 16);                   \
+          ssh[jl < NST ? jl : 0] = *reinterpret_cast<const f32x4v*>(ss + NI * Cin + ssoff[jl < NST ? jl : 0] + c * 16);        \
+        }
+        FL_SSLOAD(0) FL_SSLOAD(1) FL_SSLOAD(2) FL_SSLOAD(3) FL_SSLOAD(4)
+#undef FL_SSLOAD
+      }
+      if constexpr (q >= 0) {
+        constexpr int j = q >> 2, e = q & 3;
+        float v = stg[j][e];
+        if constexpr (PRE) v = swish_fast(v * ssc[j][e] + ssh[j][e]);
+        const float X = ((vmask >> j) & 1u) ? v * sa : 0.f;
+        const _Float16 hh = (_Float16)X;
+        sth[j][e] = hh;
+        stl[j][e] = (_Float16)(X - (float)hh);
+        if constexpr (e == 3) {
+          char* dst = smem + buf * ABUF_B;
+          *reinterpret_cast<f16x4_t*>(dst + sdst[j]) = sth[j];
+          *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = stl[j];
+        }
+      }
+    }
+  };
+
+  // ---- A fragment addresses: tile row r -> halo pixel of tap (0,0) (+ 16 B for the upper 8 channels of the lane's 16-channel
+  // group); the lane's tap of a pair: sel = 0 even member, 1 odd member
+  int abase[4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int r = wr * 64 + tm * 16 + l16;
+    const int nl = r / (RI * W), rr = r - nl * (RI * W);
+    const int oyl = rr / W, ox = rr - oyl * W;
+    abase[tm] = (nl * HR + oyl) * RPB + ox * PXB + 16 * (kg & 1);
+  }
+  const int sel = kg >> 1;
+  const int bfrag = BOFF + wc * 8192 + lane * 16;  // + slot * 16384 + tn * 2048 + piece * 1024
+
+  // ---- weight ring: pair P -> global fragments [P][16-col tile][piece][lane] x 16 B; this wave moves PPW KB of the pair's 16
+  const int nt16 = g.Cout >> 4;
+  const char* wsrc = g.wpack + H2_HDR + ((size_t)(tile_n0 >> 4) * 2048 + wid * PPW * 1024 + lane * 16);
+  const size_t pair_stride = (size_t)nt16 * 2048;
+  const int npairs = (nC >> 1) * 9;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto dma_pair = [&](int P, int slot) {
+    const int pp = P < npairs ? P : npairs - 1;  // past the end: a harmless reload into a slot nobody reads
+    const char* src = wsrc + (size_t)pp * pair_stride;
+#pragma unroll
+    for (int q = 0; q < PPW; ++q)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + q * 1024), (lptr_t)(smem + BOFF + slot * SLOT_B + (wid * PPW + q) * 1024), 16, 0, 0);
+  };
+
+  f32x4v acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  f16x8_t al[4], ah[4], bl[4], bh[4], bn[4];  // bn: b_h of the next pair
+
+  // tap s of the period (0..17): chunk s / 9 (buffer s / 9: the period starts at an even chunk), tap s % 9
+  auto tapoff = [](int s2) constexpr { return (s2 / 9) * ABUF_B + ((s2 % 9) / 3) * RPB + ((s2 % 9) % 3) * PXB; };
+
+  // ---- prologue: chunk 0 staged, pairs 0 and 1 in the ring, chunk 1 requested, a_l / b_h / b_l of pair 0 in registers
+  stage_load(0);
+  dma_pair(0, 0);
+  dma_pair(1, 1);
+  dma_pair(2, 2);
+  FL_STAGE_WAIT(3 * PPW);
+  stage_item(std::integral_constant<int, 0>{}, 0, 0);
+  stage_item(std::integral_constant<int, 1>{}, 0, 0);
+  stage_item(std::integral_constant<int, 2>{}, 0, 0);
+  stage_item(std::integral_constant<int, 3>{}, 0, 0);
+  stage_item(std::integral_constant<int, 4>{}, 0, 0);
+  stage_load(1);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"i"(PPW + NST) : "memory");  // the weights of pairs 0 and 1 have landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+    const int po = sel ? tapoff(1) : tapoff(0);
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      al[t4] = *reinterpret_cast<const f16x8_t*>(smem + PLANE_B + abase[t4] + po);
+      bh[t4] = *reinterpret_cast<const f16x8_t*>(smem + bfrag + t4 * 2048);
+      bl[t4] = *reinterpret_cast<const f16x8_t*>(smem + bfrag + t4 * 2048 + 1024);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+#define FL_I(n) std::integral_constant<int, n>{}
+#define FL_SB __builtin_amdgcn_sched_barrier(0)
+  // one pair. c = the period's even chunk. Issue order pinned by sched_barriers: MFMA first, one LDS read (or staging slot) per gap
+  auto pair = [&](auto ic, int c) {
+    constexpr int I = decltype(ic)::value;      // pair of the period, 0..8
+    constexpr int IN = (I + 1) % 9;             // next pair (of the next period when I == 8: buffers 0 | 1 again, chunk + 2)
+    const int po = sel ? tapoff(2 * I + 1) : tapoff(2 * I);
+    const int pon = sel ? tapoff(2 * IN + 1) : tapoff(2 * IN);
+    const char* Bn = smem + bfrag + (IN % 3) * SLOT_B;
+    // conversion windows: the odd chunk (c + 1 -> buffer 1) in pairs 1-2, the even chunk of the next period (c + 2 -> buffer 0) in 6-7
+    constexpr int WIN = (I == 1 || I == 2) ? 1 : ((I == 6 || I == 7) ? 2 : 0);
+    constexpr int GB = (I == 1 || I == 6) ? 0 : 48;  // first gap of this pair inside its window
+    const int cs = WIN == 1 ? (c + 1 < nC ? c + 1 : c) : (c + 2 < nC ? c + 2 : c);
+    auto SLOT = [&](auto gp) {
+      constexpr int gi = decltype(gp)::value;
+      if constexpr (WIN != 0) stage_slot(FL_I(GB + gi), WIN == 1 ? 1 : 0, cs);
+      else if constexpr (I == 0 || I == 5) {  // the pair before a window: only the first item's coefficient read (gap -1)
+        if constexpr (gi == 47) stage_slot(FL_I(-1), I == 0 ? 1 : 0, I == 0 ? (c + 1 < nC ? c + 1 : c) : (c + 2 < nC ? c + 2 : c));
+      }
+    };
+#define FL_MF(AA, BB, t)                                                                                             \
+    acc[(t) >> 2][(t) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AA[(t) >> 2], BB[(t) & 3], acc[(t) >> 2][(t) & 3], 0, 0, 0); FL_SB;
+    // piece 1: a_l b_h; under it: a_h of THIS pair
+    FL_MF(al, bh, 0) FL_MF(al, bh, 1)
+    ah[0] = *reinterpret_cast<const f16x8_t*>(smem + abase[0] + po); FL_SB; SLOT(FL_I(0)); FL_SB;
+    FL_MF(al, bh, 2)
+    ah[1] = *reinterpret_cast<const f16x8_t*>(smem + abase[1] + po); FL_SB; SLOT(FL_I(1)); FL_SB;
+    FL_MF(al, bh, 3)
+    ah[2] = *reinterpret_cast<const f16x8_t*>(smem + abase[2] + po); FL_SB; SLOT(FL_I(2)); FL_SB;
+    FL_MF(al, bh, 4)
+    ah[3] = *reinterpret_cast<const f16x8_t*>(smem + abase[3] + po); FL_SB; SLOT(FL_I(3)); FL_SB;
+#define FL_MS(AA, BB, t, gi) FL_MF(AA, BB, t) SLOT(FL_I(gi)); FL_SB;
+    FL_MS(al, bh, 5, 4) FL_MS(al, bh, 6, 5) FL_MS(al, bh, 7, 6) FL_MS(al, bh, 8, 7) FL_MS(al, bh, 9, 8) FL_MS(al, bh, 10, 9)
+    FL_MS(al, bh, 11, 10) FL_MS(al, bh, 12, 11) FL_MS(al, bh, 13, 12) FL_MS(al, bh, 14, 13) FL_MS(al, bh, 15, 14)
+    // piece 2: a_h b_l; under it: a_l and b_h of the NEXT pair (a_l is free; b_h goes to its second buffer)
+#define FL_MR(AA, BB, t, gi, dst, src)                                                                               \
+    FL_MF(AA, BB, t) dst = *reinterpret_cast<const f16x8_t*>(src); FL_SB; SLOT(FL_I(gi)); FL_SB;
+    FL_MS(ah, bl, 0, 15) FL_MS(ah, bl, 1, 16)
+    FL_MR(ah, bl, 2, 17, al[0], smem + PLANE_B + abase[0] + pon) FL_MR(ah, bl, 3, 18, al[1], smem + PLANE_B + abase[1] + pon)
+    FL_MR(ah, bl, 4, 19, al[2], smem + PLANE_B + abase[2] + pon) FL_MR(ah, bl, 5, 20, al[3], smem + PLANE_B + abase[3] + pon)
+    FL_MR(ah, bl, 6, 21, bn[0], Bn) FL_MR(ah, bl, 7, 22, bn[1], Bn + 2048)
+    FL_MR(ah, bl, 8, 23, bn[2], Bn + 4096) FL_MR(ah, bl, 9, 24, bn[3], Bn + 6144)
+    FL_MS(ah, bl, 10, 25) FL_MS(ah, bl, 11, 26) FL_MS(ah, bl, 12, 27) FL_MS(ah, bl, 13, 28) FL_MS(ah, bl, 14, 29) FL_MS(ah, bl, 15, 30)
+    // piece 3: a_h b_h; under it: b_l of the next pair, then the weight DMA three pairs ahead (and the halo loads of pairs 3 / 7)
+    FL_MS(ah, bh, 0, 31) FL_MS(ah, bh, 1, 32)
+    FL_MR(ah, bh, 2, 33, bl[0], Bn + 1024) FL_MR(ah, bh, 3, 34, bl[1], Bn + 2048 + 1024)
+    FL_MR(ah, bh, 4, 35, bl[2], Bn + 4096 + 1024) FL_MR(ah, bh, 5, 36, bl[3], Bn + 6144 + 1024)
+    FL_MS(ah, bh, 6, 37) FL_MS(ah, bh, 7, 38) FL_MS(ah, bh, 8, 39)
+    FL_MF(ah, bh, 9)
+    dma_pair((c >> 1) * 9 + I + 3, I % 3);
+    if constexpr (I == 3) stage_load(c + 2 < nC ? c + 2 : c);
+    if constexpr (I == 7) stage_load(c + 3 < nC ? c + 3 : c);
+    FL_SB;
+    SLOT(FL_I(40)); FL_SB;
+    FL_MS(ah, bh, 10, 41) FL_MS(ah, bh, 11, 42) FL_MS(ah, bh, 12, 43) FL_MS(ah, bh, 13, 44) FL_MS(ah, bh, 14, 45) FL_MS(ah, bh, 15, 46)
+    SLOT(FL_I(47)); FL_SB;
+#undef FL_MR
+#undef FL_MS
+#undef FL_MF
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) bh[t4] = bn[t4];
+    // vmcnt, oldest first at the end of pair p: DMA(p+2), [halo loads of pair p-1], DMA(p+3), [halo loads of pair p]: DMA(p+2) must
+    // have landed; the halo loads issued in pairs 3 / 7 are waited for behind pairs 5 / 0
+    if constexpr (I == 3 || I == 7 || I == 4 || I == 8) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW + NST) : "memory");
+    } else if constexpr (I == 5 || I == 0) {
+      FL_STAGE_WAIT(PPW);
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PPW) : "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    FL_SB;
+  };
+#pragma unroll 1
+  for (int c = 0; c < nC; c += 2) {
+    pair(FL_I(0), c); pair(FL_I(1), c); pair(FL_I(2), c); pair(FL_I(3), c); pair(FL_I(4), c);
+    pair(FL_I(5), c); pair(FL_I(6), c); pair(FL_I(7), c); pair(FL_I(8), c);
+  }
+#undef FL_I
+#undef FL_SB
+#undef FL_STAGE_WAIT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the block's LDS allocation
+
+  // ---- epilogue (C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg)
+  float st1[4], st2[4], bv[4];
+  const bool has_act = g.act != FL_ACT_NONE;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    st1[tn] = st2[tn] = 0.f;
+    bv[tn] = g.bias ? g.bias[tile_n0 + wc * 64 + tn * 16 + l16] : 0.f;
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = tile_m0 + wr * 64 + tm * 16 + 4 * kg + e;
+      float* yrow = g.y + (size_t)m * g.Cout + tile_n0 + wc * 64 + l16;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        float v = acc[tm][tn][e] * out_scale + bv[tn];
+        if (has_act) v = fl::apply_act(v, g.act, g.act_param);
+        yrow[tn * 16] = v;
+        st1[tn] += v;
+        st2[tn] += v * v;
+      }
+    }
+  }
+  h2p_stats_tail(g, st1, st2, tile_m0, tile_n0, wr, wc, l16, kg, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1009,6 +1419,31 @@ __global__ void h2_pack_kernel(const float* __restrict__ w, char* __restrict__ o
   const int t = (int)(gt % nt);
   const long long g16 = gt / nt;
   long long k0 = 16 * g16 + 8 * lh;  // k slots of this lane: 8*lh + j
+  if (layout == 2) {
+    // 3x3 taps, K = 9 Cin, Cin % 64 == 0, for v_mfma_f32_16x16x32_f16 (conv3x3_h2p_kernel): 1-KB unit u = [pair P][16-col tile t][piece]
+    // with P = 9 (chunk pair) + i; lane (n = lane & 15, kg = lane >> 4) holds tap s = 2 i + (kg >> 1) of the pair's 18
+    // (chunk 2 cp + s / 9, tap s % 9), channels 8 (kg & 1) .. + 7 of that 16-channel chunk
+    const int Cin = K / 9, nt16 = N >> 4;
+    const long long P = gt / nt16;  // (gt = unit pair index here: the same count of 64-lane groups, N / 16 per pair)
+    const int t16 = (int)(gt - P * nt16), kgl = lane >> 4, n = 16 * t16 + (lane & 15);
+    const int cp = (int)(P / 9), s2 = 2 * (int)(P - 9ll * cp) + (kgl >> 1);
+    const long long kk = (long long)(s2 % 9) * Cin + 16 * (2 * cp + s2 / 9) + 8 * (kgl & 1);
+    const float* row2 = w + (long long)n * K + kk;
+    const float4 p0 = *reinterpret_cast<const float4*>(row2), p1 = *reinterpret_cast<const float4*>(row2 + 4);
+    const float xx[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    f16x8_t h2, l2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float X = xx[j] * s;
+      const _Float16 hh = (_Float16)X;
+      h2[j] = hh;
+      l2[j] = (_Float16)(X - (float)hh);
+    }
+    f16x8_t* o2 = reinterpret_cast<f16x8_t*>(out + H2_HDR) + (gt * 2) * 64 + lane;
+    o2[0] = h2;
+    o2[64] = l2;
+    return;
+  }
   if (layout == 1) {
     const int Cin = K >> 4, nC8 = Cin >> 3;
     const int kg = (int)(g16 / nC8), c8 = (int)(g16 - (long long)kg * nC8);
@@ -1037,6 +1472,10 @@ void h2_set_attr() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 0, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2_kernel<W, 1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2p_kernel<W, 0, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2p_kernel<W, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2p_kernel<W, 0, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2p_kernel<W, 1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
 }
@@ -1239,10 +1678,18 @@ static int h2_pre_bytes(int ksize, int Wout, int Cin, int bm = 256) {
   return 2 * ni * Cin * (int)sizeof(float);
 }
 
+// the 3x3 convs with Cin % 64 == 0 run on the 16x16x32 pair kernel (weights packed in layout 2: fl_pack_weight_f16x2 and the launch
+// apply the same rule)
+#ifndef FL_H2_PAIRS
+#define FL_H2_PAIRS 1  // 0: timing-only A/B build that keeps every 3x3 conv on the 32x32x16 kernel (tools/build_variant_lib.sh)
+#endif
+bool conv3x3_h2_pairs(int Cin) { return FL_H2_PAIRS && Cin % 64 == 0; }
+
 int conv_h2_lds_bytes(int ksize, int Win, int Cin, bool pre) {
   const int Wout = ksize == 3 ? Win : Win / 2;
   int base;
-  if (ksize == 3) base = Wout == 32 ? H2Geom<32>::LDS_B : (Wout == 16 ? H2Geom<16>::LDS_B : H2Geom<8>::LDS_B);
+  if (ksize == 3 && conv3x3_h2_pairs(Cin)) base = Wout == 32 ? H2PGeom<32, 256>::LDS_B : (Wout == 16 ? H2PGeom<16, 256>::LDS_B : H2PGeom<8, 256>::LDS_B);
+  else if (ksize == 3) base = Wout == 32 ? H2Geom<32>::LDS_B : (Wout == 16 ? H2Geom<16>::LDS_B : H2Geom<8>::LDS_B);
   else base = Wout == 32 ? H2Geom4<32>::LDS_B : (Wout == 16 ? H2Geom4<16>::LDS_B : H2Geom4<8>::LDS_B);
   return base + (pre ? h2_pre_bytes(ksize, Wout, Cin) : 0);
 }
@@ -1287,12 +1734,26 @@ int launch_conv_h2(const float* x, const void* wpack, const float* bias, float* 
       else hipLaunchKernelGGL((conv3x3_h2_kernel<WW, 0, 128>), dim3(blocks), dim3(256), (H2Geom<WW, 128>::LDS_B + pre_b), s, g);      \
     }                                                                                                                       \
   } while (0)
+#define FL_LAUNCHP(WW)                                                                                                      \
+  do {                                                                                                                      \
+    if (bm == 256) {                                                                                                        \
+      if (prio) hipLaunchKernelGGL((conv3x3_h2p_kernel<WW, 1, 256>), dim3(blocks), dim3(512), (H2PGeom<WW, 256>::LDS_B + pre_b), s, g); \
+      else hipLaunchKernelGGL((conv3x3_h2p_kernel<WW, 0, 256>), dim3(blocks), dim3(512), (H2PGeom<WW, 256>::LDS_B + pre_b), s, g);      \
+    } else {                                                                                                                \
+      if (prio) hipLaunchKernelGGL((conv3x3_h2p_kernel<WW, 1, 128>), dim3(blocks), dim3(256), (H2PGeom<WW, 128>::LDS_B + pre_b), s, g); \
+      else hipLaunchKernelGGL((conv3x3_h2p_kernel<WW, 0, 128>), dim3(blocks), dim3(256), (H2PGeom<WW, 128>::LDS_B + pre_b), s, g);      \
+    }                                                                                                                       \
+  } while (0)
 #define FL_LAUNCH4(WW)                                                                                               \
   do {                                                                                                             \
     if (prio) hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 1>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B + pre_b, s, g);  \
     else hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 0>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B + pre_b, s, g);       \
   } while (0)
-  if (ksize == 3) {
+  if (ksize == 3 && conv3x3_h2_pairs(Cin)) {
+    if (W == 32) FL_LAUNCHP(32);
+    else if (W == 16) FL_LAUNCHP(16);
+    else FL_LAUNCHP(8);
+  } else if (ksize == 3) {
     if (W == 32) FL_LAUNCH(32);
     else if (W == 16) FL_LAUNCH(16);
     else FL_LAUNCH(8);
@@ -1302,6 +1763,7 @@ int launch_conv_h2(const float* x, const void* wpack, const float* bias, float* 
     else FL_LAUNCH4(8);
   }
 #undef FL_LAUNCH
+#undef FL_LAUNCHP
 #undef FL_LAUNCH4
   return fl::check_launch("conv_h2_kernel");
 }
@@ -1345,10 +1807,13 @@ extern "C" {
 
 size_t fl_pack_weight_f16x2_bytes(int N, int K) { return fl::pack_weight_f16x2_bytes(N, K); }
 
+int fl_conv2d_f16x2_weight_layout(int kh, int Cin) { return kh == 4 ? 1 : (fl::conv3x3_h2_pairs(Cin) ? 2 : 0); }
+
 // w: [N][K] fp32 (a packed conv weight [Cout][kh][kw][Cin]), N % 32 == 0, K % 16 == 0
 int fl_pack_weight_f16x2(const float* w, void* out, int N, int K, int layout, fl_stream_t stream) {
   FL_REQUIRE(w && out && N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, "fl_pack_weight_f16x2: N=%d (mult. of 32), K=%d (mult. of 16)", N, K);
-  FL_REQUIRE(layout == 0 || (layout == 1 && K % 128 == 0), "fl_pack_weight_f16x2: layout %d (0 = 16-k groups, 1 = 4x4 tap pairs, K = 16 Cin, Cin %% 8 == 0)", layout);
+  FL_REQUIRE(layout == 0 || (layout == 1 && K % 128 == 0) || (layout == 2 && K % 576 == 0 && N % 16 == 0),
+             "fl_pack_weight_f16x2: layout %d (0 = 16-k groups, 1 = 4x4 tap pairs, K = 16 Cin, Cin %% 8 == 0, 2 = 3x3 tap pairs of 32 k, K = 9 Cin, Cin %% 64 == 0)", layout);
   FL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0, "fl_pack_weight_f16x2: 16-byte alignment");
   return fl::pack_weight_f16x2(w, out, N, K, layout, reinterpret_cast<hipStream_t>(stream));
 }

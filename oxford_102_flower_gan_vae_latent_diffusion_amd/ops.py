@@ -266,11 +266,12 @@ def conv2d_fwd_presplit(x, wsplit, geom, bias, stride, pad, act=ACT_NONE, act_pa
 
 def pack_weight_f16x2(wp):
     """packed conv weight [O][kh][kw][I] (3x3 or 4x4) -> header + fp16 (h | l) pieces in MFMA-fragment order for
-    conv2d_fwd_f16x2 (the 4x4 kernel's k groups pair two taps x 8 channels: layout 1)."""
+    conv2d_fwd_f16x2 (fl_conv2d_f16x2_weight_layout), or a 2-D [N][K] operand of linear_fwd_f16x2 (layout 0)."""
     _chk(wp)
     N = wp.shape[0]
     K = wp.numel() // N
-    layout = 1 if (wp.dim() == 4 and wp.shape[1] == 4 and wp.shape[2] == 4) else 0
+    # conv weights: the layout the conv kernel of that shape reads (4x4: 1; 3x3: 2 = tap pairs for the 16x16x32 MFMA when Cin % 64 == 0)
+    layout = _lib.load().fl_conv2d_f16x2_weight_layout(int(wp.shape[1]), int(wp.shape[3])) if wp.dim() == 4 else 0
     out = torch.empty(_lib.load().fl_pack_weight_f16x2_bytes(N, K), dtype=torch.uint8, device=wp.device)
     _lib.call("fl_pack_weight_f16x2", _p(wp), _p(out), N, K, layout, _stream())
     return out
