@@ -125,10 +125,10 @@ def measure_dominant_kernel(dev, B, reps=10):
 
 
 KERNEL_NAMES = {
-    "h2_3x3": "conv3x3_h2_kernel<W,PRE> (3x3 s1 p1 convs of the encoder's ResidualBlocks in f16x2 split math: operands scaled by a "
-              "power of two and split into 2 fp16 pieces, 3 x v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulation; input halo split "
-              "once per 16-channel chunk at LDS staging with the producer's LayerNorm2d-apply + Swish fused in, pre-split weights "
-              "through an LDS-DMA ring)",
+    "h2_3x3": "conv3x3_h2p_kernel<W,PRE,BM> (3x3 s1 p1 convs of the encoder's ResidualBlocks in f16x2 split math: operands scaled by a "
+              "power of two and split into 2 fp16 pieces, 3 x v_mfma_f32_16x16x32_f16 per 32 k (two taps x 16 channels), fp32 "
+              "accumulation; input halo split once per 16-channel chunk at LDS staging with the producer's LayerNorm2d-apply + Swish "
+              "fused in, pre-split weights through an LDS-DMA ring; conv3x3_h2_kernel = the 32x32x16 variant for Cin % 64 != 0)",
     "h2_4x4": "conv4x4s2_h2_kernel<Wo,PRE> (4x4 s2 p1 down-sampling convs, same math; 16-wide k group = 2 taps x 8 channels)",
     "halo_3x3": "conv3x3_halo_kernel<W,TM> (r01 kernel, bf16x3 split math: 6 x v_mfma_f32_32x32x16_bf16 per 16 k)",
     "halo_4x4": "conv4x4s2_halo_kernel<Wo,TM> (r01 kernel, bf16x3 split math)",
@@ -482,7 +482,7 @@ def main():
         ops.set_gemm_math(a.gemm_math)
     gemm_math = ops.get_gemm_math()
     gemm_math_note = ("split: fp32-equivalent split math on the 16-bit matrix pipe. Frozen-encoder convs: f16x2 (operands scaled by a "
-                      "power of two, split by round-to-nearest into 2 fp16 pieces, 3 of 4 piece products on v_mfma_f32_32x32x16_f16, fp32 "
+                      "power of two, split by round-to-nearest into 2 fp16 pieces, 3 of 4 piece products on v_mfma_f32_16x16x32_f16 / 32x32x16_f16, fp32 "
                       "accumulation; error vs fp64 <= 3e-6 of the output max, 2-4x the native fp32 MFMA kernel's, tests/test_kernels_gpu.py::"
                       "test_f16x2_conv_is_fp32_equivalent). Other GEMMs: bf16x3 (3 round-to-nearest bf16 pieces, 6 of 9 piece products on "
                       "v_mfma_f32_32x32x16_bf16; ::test_split_mfma_is_fp32_equivalent). --gemm-math fp32 = native fp32 MFMA"
@@ -631,6 +631,9 @@ def main():
                 # not at the 2.4 GHz the data-sheet peak assumes
                 "issued_16bit_mfma_tflops": r["tflops"] * r["pp"] if r["pp"] else None,
                 "library_bf16_gemm_8192_tflops": library_gemm_tflops(dev),
+                # context, not the denominator of `frac`: what a bare LDS-fed f16 MFMA loop sustains on RANDOM operands under DVFS
+                # (tools/mfma_shape_probe.hip, profiles/r03_mfma_shape_probe.txt; 2149 / 1992 on zero operands)
+                "lds_fed_mfma_loop_random_operands_tflops": {"v_mfma_f32_16x16x32_f16": 1600, "v_mfma_f32_32x32x16_f16": 1432},
                 "traffic": PMC_TRAFFIC.get(dom) if B == 256 else None,
                 "traffic_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), %s" % PMC_SOURCE if PMC_TRAFFIC.get(dom) else None,
                 "algorithmic_bytes_per_launch": r["bytes_per_launch"],
