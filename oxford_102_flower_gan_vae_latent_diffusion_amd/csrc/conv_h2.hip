@@ -36,12 +36,6 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-// FL_H2_ILV=0: the round-2 main loops ([DMA, fragment reads, 12 MFMAs] per tap, staging in bursts) - kept for same-box A/B
-// timing only (tools/build_variant_lib.sh)
-#ifndef FL_H2_ILV
-#define FL_H2_ILV 1
-#endif
-
 constexpr int H2_HDR = 256;  // bytes in front of the weight fragments: [0] amax bits, [1] 2^-e_w (float)
 
 struct H2Args {
@@ -351,7 +345,7 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
     stage_item(std::integral_constant<int, 4>{}, buf, c);
   };
 
-  // The same item, cut into slots for the main loop (FL_H2_ILV): element e of item j is staging step q = 4 j + e; the chunk's
+  // The same item, cut into slots for the main loop: element e of item j is staging step q = 4 j + e; the chunk's
   // 4 NST steps are dealt over the 40 MFMA gaps of taps 3..7 (h2_step_at), an item's pre-op coefficients are read at the end
   // of the tap before its first element and its two ds_write_b64 follow its last. Pieces wait in registers (sth / stl) in between.
   f32x4v ssc[NST], ssh[NST];
@@ -418,27 +412,17 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
     f16x8_t a[2][2];  // [tm][plane]
     f16x8_t b[2][2];  // [tn][piece]
   };
-  // -DFL_H2_ABLATE=n: timing-only builds with WRONG results (tools/conv_h2_bench.py): 1 = no B fragment reads after the
-  // first tap, 2 = no A fragment reads after the first tap, 3 = neither
-#ifndef FL_H2_ABLATE
-#define FL_H2_ABLATE 0
-#endif
-  bool abl_first = true;
-  auto frag_load = [&](Frags& f, int abuf, int tapoff, int slot) {
+  auto frag_load = [&](Frags& f, int abuf, int tapoff, int slot) {  // (prologue only: the main loop reads one fragment per MFMA gap)
     const char* A = smem + abuf * ABUF_B + tapoff;
     const char* Bp = smem + bfrag + slot * SLOT_B;
-    if ((FL_H2_ABLATE & 1) == 0 || abl_first) {
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
+    for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) f.b[tn][p] = *reinterpret_cast<const f16x8_t*>(Bp + tn * 2048 + p * 1024);
-    }
-    if ((FL_H2_ABLATE & 2) == 0 || abl_first) {
+      for (int p = 0; p < 2; ++p) f.b[tn][p] = *reinterpret_cast<const f16x8_t*>(Bp + tn * 2048 + p * 1024);
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) f.a[tm][p] = *reinterpret_cast<const f16x8_t*>(A + abase[tm] + p * PLANE_B);
-    }
+      for (int p = 0; p < 2; ++p) f.a[tm][p] = *reinterpret_cast<const f16x8_t*>(A + abase[tm] + p * PLANE_B);
   };
 
   f32x16 acc[2][2];
@@ -448,19 +432,6 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-  // PRIO: s_setprio(1) / (0) around the cluster keep hipcc from moving MFMAs across the barriers (guide T5); the taps that
-  // interleave staging VALU work with their MFMAs must not have them (s_setprio fences the scheduler)
-  auto mfma12 = [&](const Frags& f, auto prio) {
-    constexpr bool PRIO = decltype(prio)::value;
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#define FL_PIECE(pa, pb)                                                                         \
-    _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) \
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm][pa], f.b[tn][pb], acc[tm][tn], 0, 0, 0);
-    FL_PIECE(1, 0) FL_PIECE(0, 1) FL_PIECE(0, 0)  // l*h, h*l, h*h: smallest terms first
-#undef FL_PIECE
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-  };
 
   // ---- prologue: chunk 0 staged, taps 0..2 of chunk 0 in the ring, fragments of tap 0 in registers
   stage_load(0);
@@ -475,14 +446,13 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
   Frags fA, fB;
   frag_load(fA, 0, 0, 0);
   fB = fA;
-  abl_first = false;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
   // one tap: DMA three taps ahead into the slot this tap's fragments came from, fragments of the next tap under this
   // tap's MFMAs, then [counted vmcnt: the DMA of tap t+2 has landed] + lgkmcnt(0) + barrier
-  // FL_H2_ILV (default): the tap OPENS with MFMAs. The r02 order [weight DMA, 8 fragment reads, 12 MFMAs] left the matrix pipe
+  // The tap OPENS with MFMAs. The r02 order [weight DMA, 8 fragment reads, 12 MFMAs] left the matrix pipe
   // empty behind every barrier while both waves of a SIMD issued their DMA piece (60-180 cycles) and their reads; now the
   // first two MFMAs go out at once, one fragment read of the next tap follows each of the next eight, and the DMA piece (and
   // the halo loads of tap 0) sit behind MFMA 9. Every step is pinned by a sched_barrier: the order below is the issue order.
@@ -490,7 +460,6 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
     constexpr int T = decltype(tap_c)::value;
     constexpr int T3 = (T + 3) % 9, C3 = (T + 3) / 9;        // tap t+3
     constexpr int T1 = (T + 1) % 9, C1 = (T + 1) / 9;        // tap t+1
-#if FL_H2_ILV
     const char* An = smem + ((c + C1) & 1) * ABUF_B + (T1 / 3) * RPB + (T1 % 3) * PXB;
     const char* Bn = smem + bfrag + (T1 % 3) * SLOT_B;
     auto MF = [&](auto ic) {  // MFMA i of the tap's twelve: pieces l*h, h*l, h*h (smallest first) x (tm, tn)
@@ -518,23 +487,6 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
     MF(FL_I(10)); FL_SB; MF(FL_I(11)); FL_SB;
 #undef FL_I
 #undef FL_SB
-#else
-    dma_tap(c + C3, T3, T % 3);
-    if constexpr (T == 0) stage_load(c + 1 < nC ? c + 1 : c);
-    frag_load(nxt, (c + C1) & 1, (T1 / 3) * RPB + (T1 % 3) * PXB, T1 % 3);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (T >= 3 && T < 3 + NST) {  // staging item T - 3 of the NEXT chunk, interleaved with this tap's MFMAs
-      stage_item(std::integral_constant<int, T - 3>{}, (c + 1) & 1, c + 1 < nC ? c + 1 : c);
-      mfma12(cur, std::false_type{});
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-      }
-    } else {
-      mfma12(cur, std::true_type{});
-    }
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (T == 0 || T == 1) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST + PPW) : "memory");
@@ -1033,7 +985,6 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
     __syncthreads();
   }
 
-#if FL_H2_ILV
   // Halo loads cover TWO chunks (16 channels = 64 contiguous bytes per pixel, two 16-byte loads per thread issued back to back):
   // a chunk's 8 channels alone are 32-byte pieces of a pixel row, and fetching a row's two halves a chunk apart cost down1 1.6x
   // its algorithmic traffic. stg[0][j] = channels 0..7 of the pair (an even chunk), stg[1][j] = channels 8..15 (the odd chunk).
@@ -1121,51 +1072,6 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
       }
     }
   };
-#else
-  f32x4v stg[NST];
-  auto stage_load = [&](int c) {
-    const float* xc = g.x + c * 8;
-#pragma unroll
-    for (int j = 0; j < NST; ++j) {
-      const float* p = xc + goff[j];
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg[j]) : "v"(p) : "memory");
-    }
-  };
-#define FL_STAGE_WAIT4(N)                                                                                                    \
-  do {                                                                                                                       \
-    if constexpr (NST == 5)                                                                                                  \
-      asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4])::"memory"); \
-    else                                                                                                                     \
-      asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                 \
-                   : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[NST - 1])::"memory");      \
-  } while (0)
-  auto stage_store = [&](int buf, int c) {  // c: the chunk in the staging registers
-    char* dst = smem + buf * ABUF_B;
-#pragma unroll
-    for (int j = 0; j < NST; ++j) {
-      if (sdst[j] < 0) continue;
-      const bool ok = (vmask >> j) & 1u;
-      f32x4v v = stg[j];
-      if constexpr (PRE) {
-        const f32x4v sc = *reinterpret_cast<const f32x4v*>(ss + ssoff[j] + c * 8);
-        const f32x4v sh = *reinterpret_cast<const f32x4v*>(ss + NI * Cin + ssoff[j] + c * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = swish_fast(v[e] * sc[e] + sh[e]);
-      }
-      f16x4_t h, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float X = ok ? v[e] * sa : 0.f;
-        const _Float16 hh = (_Float16)X;
-        h[e] = hh;
-        l[e] = (_Float16)(X - (float)hh);
-      }
-      *reinterpret_cast<f16x4_t*>(dst + sdst[j]) = h;
-      *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = l;
-    }
-  };
-
-#endif
 
   // A fragment address of k group (ky, kp): this lane's tap is (ky, 2 kp + lh) -> column parity lh, entry ox + kp
   int abase[2];
@@ -1214,17 +1120,7 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  auto mfma12 = [&](const Frags& f) {
-    __builtin_amdgcn_s_setprio(1);
-#define FL_PIECE(pa, pb)                                                                         \
-    _Pragma("unroll") for (int tm = 0; tm < 2; ++tm) _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) \
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm][pa], f.b[tn][pb], acc[tm][tn], 0, 0, 0);
-    FL_PIECE(1, 0) FL_PIECE(0, 1) FL_PIECE(0, 0)
-#undef FL_PIECE
-    __builtin_amdgcn_s_setprio(0);
-  };
 
-#if FL_H2_ILV
   // ---- prologue: chunk pair 0 loaded, its even half staged, k groups 0..3 in the ring, fragments of group 0 in registers
   stage_load(0);
   dma_grp(0, 0, 0);
@@ -1306,67 +1202,6 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
   }
 #undef FL_STAGE_WAIT4
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-  // ---- prologue: chunk 0 staged, k groups 0..3 in the ring, fragments of group 0 in registers
-  stage_load(0);
-  dma_grp(0, 0, 0);
-  dma_grp(0, 1, 1);
-  dma_grp(0, 2, 2);
-  dma_grp(0, 3, 3);
-  FL_STAGE_WAIT4(4);
-  stage_store(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  Frags fA, fB;
-  frag_load(fA, 0, 0, 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  // one k group: DMA four groups ahead into the slot this group's fragments came from; fragments of the next group under
-  // this group's MFMAs; [counted vmcnt: the DMA of group t+2 has landed] + lgkmcnt(0) + barrier
-  auto grp = [&](auto grp_c, Frags& cur, Frags& nxt, int c) {
-    constexpr int T = decltype(grp_c)::value;
-    constexpr int T4 = (T + 4) % 8, C4 = (T + 4) / 8;
-    constexpr int T1 = (T + 1) % 8, C1 = (T + 1) / 8;
-    dma_grp(c + C4, T4, T % 4);
-    if constexpr (T == 0) stage_load(c + 1 < nC ? c + 1 : c);
-    frag_load(nxt, (c + C1) & 1, (T1 >> 1) * RPB + (T1 & 1) * PXB, T1 % 4);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma12(cur);
-    __builtin_amdgcn_sched_barrier(0);
-    // outstanding, oldest first, at the end of group t: DMA(t+2) [issued at t-2], DMA(t+3), DMA(t+4) - and the NST halo
-    // loads issued at t = 0 right after DMA(4)
-    if constexpr (T == 0 || T == 1 || T == 2) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NST + 2) : "memory");
-    } else if constexpr (T == 3) {
-      FL_STAGE_WAIT4(2);  // the halo loads are older than DMA(t+2) now: complete
-    } else {
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    }
-    if constexpr (T == 4) stage_store((c + 1) & 1, c + 1 < nC ? c + 1 : c);  // the other buffer: last read while group 6 of the previous chunk ran
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto chunk = [&](int c) {  // 8 groups: the register sets alternate and come back to fA
-    grp(std::integral_constant<int, 0>{}, fA, fB, c);
-    grp(std::integral_constant<int, 1>{}, fB, fA, c);
-    grp(std::integral_constant<int, 2>{}, fA, fB, c);
-    grp(std::integral_constant<int, 3>{}, fB, fA, c);
-    grp(std::integral_constant<int, 4>{}, fA, fB, c);
-    grp(std::integral_constant<int, 5>{}, fB, fA, c);
-    grp(std::integral_constant<int, 6>{}, fA, fB, c);
-    grp(std::integral_constant<int, 7>{}, fB, fA, c);
-  };
-#pragma unroll 1
-  for (int c = 0; c < nC; ++c) chunk(c);
-#undef FL_STAGE_WAIT4
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-#endif
 
   float st1[2], st2[2], bv[2];
   const bool has_act = g.act != FL_ACT_NONE;
