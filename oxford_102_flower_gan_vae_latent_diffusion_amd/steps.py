@@ -135,12 +135,12 @@ class FusedAdam:
         fp.bump()
 
 
-def allreduce_grads(fp, world_size, group=None):
+def allreduce_grads(fp, world_size, group=None, force=False):
     """The ONE collective of a data-parallel step: sum the flat active-gradient buffer over ranks (RCCL over xGMI
     when the buffer lives on a GPU, gloo in the CPU tests). The 1/world factor is applied by the caller (folded into
     the clip/Adam kernel), so that mean-of-shard-gradients == global-batch gradient (the loss is a batch mean,
     v2:298)."""
-    if world_size > 1:
+    if world_size > 1 or force:   # force: a one-rank group rehearsing the data-parallel path (tests)
         import torch.distributed as dist
         dist.all_reduce(fp.grad[:fp.n_active], group=group)
     return fp.grad[:fp.n_active]
@@ -545,14 +545,17 @@ class VAEGANTrainer:
         fl_batchnorm_*_from_sums), so the statistics, the running buffers and dx are those of the global batch.
         sync_bn=False keeps the LOCAL shard statistics (what torch DDP does without SyncBatchNorm); the adversarial
         gradients then differ from a single-process run on the global batch.
-    Collectives are eager torch.distributed calls (RCCL on GPUs), so the data-parallel step is not graph-captured."""
+    The collectives are torch.distributed calls on the step's stream: with RCCL (backend "nccl") capture() records them into the
+    step's hipGraph like any kernel (round 3; a gloo group cannot be captured: step() only). force_collectives=True runs the
+    data-parallel code path on a ONE-rank group - the rehearsal the one-GPU test box allows (tests/test_vaegan_dp_gpu.py)."""
 
     def __init__(self, autoencoder, discriminator, vgg, lr=1e-4, lambda_cls=0.1, lambda_center=0.05, lambda_vgg=0.4,
-                 lambda_gan=0.2, process_group=None, world_size=1, sync_bn=True):
+                 lambda_gan=0.2, process_group=None, world_size=1, sync_bn=True, force_collectives=False):
         self.ae, self.disc, self.vgg = autoencoder, discriminator, vgg
         self.pg, self.world = process_group, int(world_size)
+        self.dp = self.world > 1 or bool(force_collectives)
         self.bn_sync = None
-        if self.world > 1 and sync_bn:
+        if self.dp and sync_bn:
             import torch.distributed as dist
             self.bn_sync = lambda t: dist.all_reduce(t, group=self.pg)
         dev = next(autoencoder.parameters()).device
@@ -570,8 +573,11 @@ class VAEGANTrainer:
     def capture(self, data, labels, epoch=0, num_epochs=300):
         """Capture the whole step (one loss phase = one graph) as a hipGraph; `data`/`labels` become the static input
         buffers. replay() after copying a new batch into them."""
-        if self.world > 1:
-            raise RuntimeError("the data-parallel VAE-GAN step issues eager collectives: call step(), not capture()")
+        if self.dp:
+            import torch.distributed as dist
+            if dist.get_backend(self.pg) != "nccl":
+                raise RuntimeError("only RCCL collectives (backend 'nccl') can be captured into the step's hipGraph: with %r call step(), "
+                                   "not capture()" % dist.get_backend(self.pg))
         self.static_data, self.static_labels = data, labels
         for _ in range(2):
             self.step(data, labels, epoch=epoch, num_epochs=num_epochs)
@@ -646,13 +652,13 @@ class VAEGANTrainer:
         Gf, _ = engine_bwd.disc_bwd(D, S_f, ops.bce_bwd(p_fake, 0.0, 0.5), need_wgrad=True, need_dx=False)
         self.dfp.set_grads(Gr)
         self.dfp.add_grads(Gf)
-        allreduce_grads(self.dfp, W, self.pg)
+        allreduce_grads(self.dfp, W, self.pg, force=self.dp)
         self.d_opt.step(gscale=1.0 / W)
         # ---- generator adversarial term with the UPDATED discriminator (v2:1105) ----
         p_adv, S_a = engine_bwd.disc_fwd(D, recon, **bns)
         adv = ops.bce_fwd(p_adv, 1.0)
         # ---- device-side loss balancing (v2:1107-1125) ----
-        if W > 1:
+        if self.dp:
             import torch.distributed as dist
             # [recon, percep, kl mean part, adv, ce, centre | kl batch-sum part | d_loss]: means are averaged, the sum is summed
             tv = torch.zeros(8, dtype=torch.float32, device=self.dev)
@@ -695,13 +701,13 @@ class VAEGANTrainer:
         G_enc, _ = engine_bwd.encoder_bwd(ae.encoder, S_enc, dmu, dlv)
         self.fp.set_grads(G_enc, "encoder.")
         self.fp.set_grads(G_dec, "decoder.")
-        if W > 1:
+        if self.dp:
             import torch.distributed as dist
             dist.all_reduce(self.fp.grad[:n_act], group=self.pg)
         self.opt.step(gscale=1.0 / W, n=n_act)                   # clip 1.0 + AdamW (v2:1128-1129)
         if epoch >= 60 and cenf > 0:                             # v2:1132-1134
             zc, lc = z, labels
-            if W > 1:  # every rank applies the EMA of the global batch: gather (sum of disjoint slices: any backend)
+            if self.dp:  # every rank applies the EMA of the global batch: gather (sum of disjoint slices: any backend)
                 import torch.distributed as dist
                 r = dist.get_rank(self.pg)
                 zc = torch.zeros(W * B, z.shape[1], dtype=torch.float32, device=self.dev)

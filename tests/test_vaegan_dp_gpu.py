@@ -117,3 +117,68 @@ def test_dp_vae_gan_step_equals_global_batch_step(dev, lambda_gan):
         assert torch.equal(ret[0]["params"][k], ret[1]["params"][k]), "ranks diverged: " + k
     for k in ret[0]["d_state"]:
         assert torch.equal(ret[0]["d_state"][k], ret[1]["d_state"][k]), "ranks diverged (D): " + k
+
+
+def _capture_worker(rank, world, port, ret):
+    import faulthandler
+    faulthandler.enable()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from oracle import procedural_init as pinit
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M, steps
+    dev = torch.device("cuda:0")
+    data, labels, _, _, _ = _inputs()
+    data, labels = data.to(dev), labels.to(dev)
+
+    def make(dp):
+        ae = M.SimpleAutoencoder()
+        ae.load_state_dict(pinit.procedural_state_dict(ae.state_dict(), 42))
+        D = M.Discriminator64()
+        D.load_state_dict(pinit.procedural_state_dict(D.state_dict(), 43))
+        ae, D = ae.to(dev).train(), D.to(dev).train()
+        for r in (ae.rng,):
+            r.manual_seed(11)
+        vgg = M.VGGPerceptualLoss(dev, state_dict=pinit.procedural_state_dict(pinit.vgg16_features16_shapes(""), 7))
+        kw = dict(process_group=dist.group.WORLD, world_size=world, force_collectives=True) if dp else {}
+        return ae, D, steps.VAEGANTrainer(ae, D, vgg, lr=1e-4, lambda_gan=0.2, **kw)
+
+    res = {}
+    for name, dp, graph in (("dp_eager", True, False), ("dp_graph", True, True), ("single", False, False)):
+        ae, D, tr = make(dp)
+        if graph:
+            tr.capture(data, labels, epoch=200, num_epochs=300)   # 2 warm-up steps + capture (the capture itself runs nothing)
+            for _ in range(2):
+                out = tr.replay()
+        else:
+            for _ in range(4):
+                out = tr.step(data, labels, epoch=200, num_epochs=300)
+        torch.cuda.synchronize()
+        res[name] = dict(total=float(out["total"]), d_loss=float(out["d_loss"]),
+                         w=ae.state_dict()["encoder.res2.conv1.weight"].detach().cpu().reshape(-1)[:4096].clone(),
+                         dw=D.state_dict()["model.2.weight"].detach().cpu().reshape(-1)[:4096].clone(),
+                         rm=D.state_dict()["model.3.running_mean"].detach().cpu().clone(),
+                         centers=ae.class_centers.detach().cpu().clone())
+    ret[rank] = res
+    dist.destroy_process_group()
+
+
+def test_dp_vae_gan_step_captures_with_rccl(dev):
+    """the data-parallel VAE-GAN step inside ONE hipGraph, RCCL collectives included (18 SyncBatchNorm
+    exchanges, the loss-term all-reduce, both gradient all-reduces, the centre gather). A test box has one GPU and RCCL refuses two
+    ranks on one device, so the data-parallel code path runs on a ONE-rank RCCL group (force_collectives): 2 warm-up steps + 2
+    replays of the captured step == 4 eager steps of the same path bit for bit, and both agree with the plain single-GPU trainer
+    (same batch; SyncBatchNorm's sums-then-statistics arithmetic differs from the fused single-GPU kernel in the last bits)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_capture_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    r = ret[0]
+    e, g, s1 = r["dp_eager"], r["dp_graph"], r["single"]
+    assert e["total"] == g["total"] and e["d_loss"] == g["d_loss"]
+    for k in ("w", "dw", "rm", "centers"):
+        assert torch.equal(e[k], g[k]), k
+    assert abs(e["total"] - s1["total"]) <= 1e-4 * abs(s1["total"]) and abs(e["d_loss"] - s1["d_loss"]) <= 1e-4
+    assert (e["rm"] - s1["rm"]).abs().max().item() <= 1e-5 * max(1.0, s1["rm"].abs().max().item())
