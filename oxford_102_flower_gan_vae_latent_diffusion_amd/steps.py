@@ -154,7 +154,8 @@ def shard_seed(base, rank):
 class DDPMTrainer:
     """Latent-DDPM training step (configs 3/4 of BASELINE.json)."""
 
-    def __init__(self, autoencoder, unet, lr=1e-3, n_steps=1000, process_group=None, world_size=1, persistent=None):
+    def __init__(self, autoencoder, unet, lr=1e-3, n_steps=1000, process_group=None, world_size=1, persistent=None,
+                 force_collectives=False):
         """persistent: run the denoiser forward/backward and clip+AdamW as persistent phase programs (program_train.py:
         2 launches instead of ~240; they need the whole device, so nothing else may run next to them). None = the
         FL_TRAIN_PROGRAM environment variable (default on)."""
@@ -173,6 +174,9 @@ class DDPMTrainer:
         self.fp = FlatParams(unet, inactive)
         self.opt = FusedAdam(self.fp, lr, weight_decay=1e-5, decoupled=True, max_norm=1.0)
         self.pg, self.world = process_group, world_size
+        # force_collectives: issue the gradient all-reduce on a ONE-rank group too - the rehearsal of the N > 1 schedule on real RCCL
+        # that a one-GPU box allows (tests/test_ddpm_dp_gpu.py)
+        self.dp = world_size > 1 or bool(force_collectives)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.eps_theta = None
         self.graph = None
@@ -251,7 +255,7 @@ class DDPMTrainer:
         return prog
 
     def allreduce(self):
-        allreduce_grads(self.fp, self.world, self.pg)
+        allreduce_grads(self.fp, self.world, self.pg, force=self.dp)
 
     @torch.no_grad()
     def update(self):
@@ -288,10 +292,10 @@ class DDPMTrainer:
         with torch.cuda.graph(self.g1):
             z = self.encode(self.static_data)
             self.fwd_bwd(z, self.static_labels)
-            if self.world == 1:   # nothing sits between the gradients and the update: one graph launch per step instead of two
+            if not self.dp:   # nothing sits between the gradients and the update: one graph launch per step instead of two
                 self.update()
         self.g2 = None
-        if self.world > 1:
+        if self.dp:
             self.g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g2, pool=self.g1.pool()):
                 self.update()
@@ -359,7 +363,7 @@ class DDPMTrainer:
         self.lab_in.copy_(self.lab_next)
         self.gU.replay()
         work = None
-        if self.world > 1:
+        if self.dp:
             import torch.distributed as dist
             work = dist.all_reduce(self.fp.grad[:self.fp.n_active], group=self.pg, async_op=True)
         self.static_data.copy_(next_data)
@@ -385,7 +389,7 @@ class DDPMTrainer:
             e0, e1 = ev(), ev()
             torch.cuda.synchronize(dev)
             e0.record()
-            if self.world > 1:
+            if self.dp:
                 import torch.distributed as dist
                 dist.all_reduce(self.fp.grad[:n], group=self.pg)
             e1.record()
@@ -403,7 +407,7 @@ class DDPMTrainer:
                 self.gU.replay()
                 e1.record()
                 work = None
-                if self.world > 1:
+                if self.dp:
                     import torch.distributed as dist
                     work = dist.all_reduce(self.fp.grad[:n], group=self.pg, async_op=True)
                 self.static_data.copy_(batches[i % len(batches)])

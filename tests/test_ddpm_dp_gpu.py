@@ -167,3 +167,69 @@ def test_dp_ddpm_overlapped_schedule_two_ranks(dev):
         assert c["world"] == 2 and c["allreduce_ms"] > 0 and c["allreduce_exposed_ms"] >= 0 and c["allreduce_bytes"] > 4e7
     assert torch.equal(ret[0]["over_flat"], ret[1]["over_flat"]), "ranks diverged"
     assert ret[0]["over_loss"] != ret[1]["over_loss"]   # per-rank noise
+
+
+def _rccl_worker(rank, world, port, ret):
+    import faulthandler
+    faulthandler.enable()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from oracle import procedural_init as pinit
+    from oxford_102_flower_gan_vae_latent_diffusion_amd import modules as M, steps
+    dev = torch.device("cuda:0")
+    B, n = 32, 4
+    g = torch.Generator().manual_seed(7)
+    data = [(torch.rand(B, 3, 64, 64, generator=g) * 2 - 1).to(dev) for _ in range(n + 1)]
+    labels = [torch.randint(0, 102, (B,), generator=g).to(dev) for _ in range(n + 1)]
+
+    def make(dp):
+        ae, un = M.SimpleAutoencoder(), M.ConditionalUNet()
+        ae.load_state_dict(pinit.procedural_state_dict(ae.state_dict(), 42))
+        un.load_state_dict(pinit.procedural_state_dict(un.state_dict(), 44))
+        ae, un = ae.to(dev).eval(), un.to(dev).train()
+        kw = dict(process_group=dist.group.WORLD, world_size=world, force_collectives=True) if dp else {}
+        tr = steps.DDPMTrainer(ae, un, lr=1e-3, persistent=True, **kw)
+        reseed(ae, un, tr)
+        return ae, un, tr
+
+    def reseed(ae, un, tr):
+        for r, s_ in ((ae.rng, 1), (un.rng, 2), (tr.diffusion.rng, 3)):
+            r.manual_seed(s_)
+
+    ae, un, tr = make(False)
+    la = [float(tr.step(data[i], labels[i])) for i in range(n)]
+    pa = tr.fp.flat.clone()
+    ae, un, tr = make(True)
+    sd0 = {k: v.clone() for k, v in un.state_dict().items()}
+    tr.capture_overlapped(data[0].clone(), labels[0].clone())
+    un.load_state_dict(sd0)
+    tr.opt.m.zero_(); tr.opt.v.zero_(); tr.opt.step_count.zero_()
+    reseed(ae, un, tr)
+    tr.prime_overlapped(data[0], labels[0])
+    lb = []
+    for i in range(n):
+        l = tr.replay_overlapped(data[i + 1], labels[i + 1])
+        torch.cuda.synchronize()
+        lb.append(float(l))
+    tr.check_programs()
+    same = bool(torch.equal(tr.fp.flat, pa))
+    comm = tr.measure_comm(data, labels, steps_n=3)   # (runs further steps)
+    ret[rank] = dict(la=la, lb=lb, same=same, comm=comm)
+    dist.destroy_process_group()
+
+
+def test_ddpm_overlapped_schedule_on_rccl_one_rank(dev):
+    """What `bench.py --gpus N` runs per rank - persistent denoiser programs, the flat-gradient all-reduce issued asynchronously on
+    RCCL's stream under the next batch's encoder graph, work.wait(), optimizer program - on REAL RCCL. A test box has one GPU (and RCCL
+    refuses two ranks on one device), so the group has one rank: the collective is trivial, the stream / event / graph choreography
+    around it is the bench's. Bit-identical to plain step() on the same batches."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    r = ret[0]
+    assert r["lb"] == r["la"] and r["same"]
+    assert r["comm"]["allreduce_ms"] > 0 and r["comm"]["allreduce_bytes"] > 4e7
