@@ -1229,6 +1229,316 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
   h2_stats_tail(g, st1, st2, tile_m0, tile_n0, wr, wc, li, lh, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The 4x4 / stride 2 convolution on v_mfma_f32_16x16x32_f16 (see conv3x3_h2p_kernel for why that shape). A 32-wide k step is one
+// kernel row ky of an 8-channel chunk: lane group g = lane >> 4 takes tap (ky, kx = g) - column parity plane g & 1, entry + (g >> 1),
+// a per-lane constant. The weights are read from pack layout 1 AS IT IS (two 16-k groups (ky, kp = 0 | 1) per step: lane (n, g) finds
+// its 16 bytes at group g >> 1, lane (g & 1) * 32 + column), so the 32x32x16 kernel above stays usable on the same pack where this
+// one does not fit (W_o = 8 with a fused pre-op: ring + coefficients exceed the LDS). Four steps per chunk, one barrier per step,
+// fragment sets retired piecewise as in the 3x3 pair kernel; chunk c + 1 is converted in steps 0-1 of chunk c; an even chunk issues
+// the halo loads of the next chunk PAIR in step 2 and waits for them behind step 3. Ring: 3 slots of 16 KB, slot index at run time
+// (8 steps per loop period is not a multiple of 3).
+template <int WO>
+struct H2PGeom4 : H2Geom4<WO> {
+  static constexpr int NS = 3, SLOT_B = 16384, BOFF = 2 * H2Geom4<WO>::ABUF_B;
+  static constexpr int LDS_B = BOFF + NS * SLOT_B;
+};
+
+template <int WO, int PRE>
+__global__ __launch_bounds__(512, 2) void conv4x4s2_h2p_kernel(const H2Args g) {
+  using G = H2PGeom4<WO>;
+  constexpr int BM = G::BM, BN = G::BN, W = G::W, RI = G::RI, NI = G::NI, HR = G::HR, HC = G::HC, PXB = G::PXB, RPB = G::RPB;
+  constexpr int PAR_B = G::PAR_B, PLANE_B = G::PLANE_B, ABUF_B = G::ABUF_B, BOFF = G::BOFF, SLOT_B = G::SLOT_B;
+  constexpr int ITEMS = G::ITEMS, NT = G::NT, NST = G::NST;
+  static_assert(NST == 5 || NST == 6, "staging passes");
+  constexpr int NGAP = 88;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l16 = lane & 15, kg = lane >> 4;
+
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile_m0 = (tile / g.tiles_n) * BM;
+  const int tile_n0 = (tile % g.tiles_n) * BN;
+  const int img0 = tile_m0 / (WO * WO);
+  const int oy0 = (tile_m0 - img0 * (WO * WO)) / WO;
+  const int Cin = g.Cin, nC = Cin >> 3;  // 8-channel chunks; nC is even
+
+  const int ea = g.a_amax ? scale_exp_from_amax(*g.a_amax) : g.a_exp;
+  const float sa = __uint_as_float((unsigned)(ea + 127) << 23);
+  const float out_scale = reinterpret_cast<const float*>(g.wpack)[1] * __uint_as_float((unsigned)(127 - ea) << 23);
+
+  int goff[NST], sdst[NST], ssoff[NST];
+  unsigned vmask = 0u;
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const int i0 = tid + NT * j, i = i0 < ITEMS ? i0 : i0 - ITEMS;  // (threads past the last item repeat item i - ITEMS)
+    const int pix = i >> 1, c4 = i & 1;
+    const int nl = pix / (HR * HC), rem = pix - nl * (HR * HC);
+    const int hy = rem / HC, hx = rem - hy * HC;
+    const int iy = 2 * oy0 - 1 + hy, ix = hx - 1;
+    const bool ok = ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
+    goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
+    sdst[j] = (hx & 1) * PAR_B + (nl * HR + hy) * RPB + (hx >> 1) * PXB + c4 * 8;
+    ssoff[j] = (nl < NI ? nl : 0) * Cin + c4 * 4;
+    vmask |= (ok ? 1u : 0u) << j;
+  }
+  float* ss = reinterpret_cast<float*>(smem + G::LDS_B);
+  if constexpr (PRE) {
+    for (int i = tid; i < NI * Cin; i += NT) {
+      const int nl = i / Cin, ch = i - nl * Cin;
+      ss[i] = g.pre_scale[(size_t)(img0 + nl) * Cin + ch];
+      ss[NI * Cin + i] = g.pre_shift[(size_t)(img0 + nl) * Cin + ch];
+    }
+    __syncthreads();
+  }
+
+  f32x4v stg[2][NST];  // [half of the chunk pair][item]
+  auto stage_load = [&](int sc) {
+    const float* xc = g.x + sc * 16;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const float* p = xc + goff[j];
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:32"
+                   : "=&v"(stg[0][j]), "=&v"(stg[1][j]) : "v"(p) : "memory");
+    }
+  };
+#define FL_STAGE_WAIT4(N)                                                                                                    \
+  do {                                                                                                                       \
+    if constexpr (NST == 5)                                                                                                  \
+      asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                 \
+                   : "+v"(stg[0][0]), "+v"(stg[0][1]), "+v"(stg[0][2]), "+v"(stg[0][3]), "+v"(stg[0][4]),                       \
+                     "+v"(stg[1][0]), "+v"(stg[1][1]), "+v"(stg[1][2]), "+v"(stg[1][3]), "+v"(stg[1][4])                        \
+                   ::"memory");                                                                                              \
+    else                                                                                                                     \
+      asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                 \
+                   : "+v"(stg[0][0]), "+v"(stg[0][1]), "+v"(stg[0][2]), "+v"(stg[0][3]), "+v"(stg[0][4]), "+v"(stg[0][NST - 1]), \
+                     "+v"(stg[1][0]), "+v"(stg[1][1]), "+v"(stg[1][2]), "+v"(stg[1][3]), "+v"(stg[1][4]), "+v"(stg[1][NST - 1])  \
+                   ::"memory");                                                                                              \
+  } while (0)
+  auto stage_store = [&](int buf, int c) {  // prologue only: chunk c (0) = the even half of the pair in the staging registers
+    char* dst = smem + buf * ABUF_B;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const bool ok = (vmask >> j) & 1u;
+      f32x4v v = stg[0][j];
+      if constexpr (PRE) {
+        const f32x4v sc = *reinterpret_cast<const f32x4v*>(ss + ssoff[j] + c * 8);
+        const f32x4v sh = *reinterpret_cast<const f32x4v*>(ss + NI * Cin + ssoff[j] + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = swish_fast(v[e] * sc[e] + sh[e]);
+      }
+      f16x4_t h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float X = ok ? v[e] * sa : 0.f;
+        const _Float16 hh = (_Float16)X;
+        h[e] = hh;
+        l[e] = (_Float16)(X - (float)hh);
+      }
+      *reinterpret_cast<f16x4_t*>(dst + sdst[j]) = h;
+      *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = l;
+    }
+  };
+  f32x4v ssc[NST], ssh[NST];
+  f16x4_t sth[NST], stl[NST];
+  auto stage_slot = [&](auto gc, auto hc, int buf, int c) {  // gap G_ of the conversion window, half HALF of the staged pair
+    constexpr int G_ = decltype(gc)::value, HALF = decltype(hc)::value;
+    if constexpr (G_ >= -1 && G_ < NGAP) {
+      constexpr int q = G_ >= 0 ? h2p_step_at(G_, 4 * NST, NGAP) : -1;
+      if constexpr (PRE) {
+#define FL_SSLOAD(jl)                                                                                                         \
+        if constexpr (jl < NST && h2p_ssload_pos(jl < NST ? jl : 0, NST, NGAP) == G_) {                                        \
+          ssc[jl < NST ? jl : 0] = *reinterpret_cast<const f32x4v*>(ss + ssoff[jl < NST ? jl : 0] + c * 8);                    \
+          ssh[jl < NST ? jl : 0] = *reinterpret_cast<const f32x4v*>(ss + NI * Cin + ssoff[jl < NST ? jl : 0] + c * 8);         \
+        }
+        FL_SSLOAD(0) FL_SSLOAD(1) FL_SSLOAD(2) FL_SSLOAD(3) FL_SSLOAD(4) FL_SSLOAD(5)
+#undef FL_SSLOAD
+      }
+      if constexpr (q >= 0) {
+        constexpr int j = q >> 2, e = q & 3;
+        float v = stg[HALF][j][e];
+        if constexpr (PRE) v = swish_fast(v * ssc[j][e] + ssh[j][e]);
+        const float X = ((vmask >> j) & 1u) ? v * sa : 0.f;
+        const _Float16 hh = (_Float16)X;
+        sth[j][e] = hh;
+        stl[j][e] = (_Float16)(X - (float)hh);
+        if constexpr (e == 3) {
+          char* dst = smem + buf * ABUF_B;
+          *reinterpret_cast<f16x4_t*>(dst + sdst[j]) = sth[j];
+          *reinterpret_cast<f16x4_t*>(dst + PLANE_B + sdst[j]) = stl[j];
+        }
+      }
+    }
+  };
+
+  // A fragment base of this lane: tap kx = kg -> parity plane kg & 1, entry ox + (kg >> 1); a step adds ky * RPB
+  int abase[4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int r = wr * 64 + tm * 16 + l16;
+    const int nl = r / (RI * WO), rr = r - nl * (RI * WO);
+    const int oyl = rr / WO, ox = rr - oyl * WO;
+    abase[tm] = (kg & 1) * PAR_B + (nl * HR + 2 * oyl) * RPB + (ox + (kg >> 1)) * PXB;
+  }
+  // B fragment of 16-col tile tn, piece p (pack layout 1 in the slot: [kp][32-col tile][piece][lane] x 16 B)
+  const int bfrag = BOFF + (kg >> 1) * 8192 + ((kg & 1) * 32 + l16) * 16 + wc * 4096;  // + slot * 16384 + (tn >> 1) * 2048 + (tn & 1) * 256 + p * 1024
+
+  const int nt32 = g.Cout >> 5;
+  const char* wsrc = g.wpack + H2_HDR + ((size_t)(tile_n0 >> 5) * 128 + wid * 64 + lane) * 16;
+  const size_t g16_stride = (size_t)nt32 * 128 * 16;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto dma_step = [&](int c, int ky, int slot) {  // both 16-k groups (ky, kp) of chunk c; this wave's KB of each
+    const int cc = c < nC ? c : nC - 1;
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      const char* src = wsrc + (size_t)((2 * ky + kp) * nC + cc) * g16_stride;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + BOFF + slot * SLOT_B + kp * 8192 + wid * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4v acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  f16x8_t al[4], ah[4], bl[4], bh[4], bn[4];
+
+  // ---- prologue
+  stage_load(0);
+  dma_step(0, 0, 0);
+  dma_step(0, 1, 1);
+  dma_step(0, 2, 2);
+  FL_STAGE_WAIT4(6);
+  stage_store(0, 0);
+  stage_slot(std::integral_constant<int, -1>{}, std::integral_constant<int, 1>{}, 1, nC > 1 ? 1 : 0);  // (the first window's coefficient reads)
+  asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // the weights of steps 0 and 1 have landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    al[t4] = *reinterpret_cast<const f16x8_t*>(smem + PLANE_B + abase[t4]);
+    bh[t4] = *reinterpret_cast<const f16x8_t*>(smem + bfrag + (t4 >> 1) * 2048 + (t4 & 1) * 256);
+    bl[t4] = *reinterpret_cast<const f16x8_t*>(smem + bfrag + (t4 >> 1) * 2048 + (t4 & 1) * 256 + 1024);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  int sl = 0;  // ring slot of the running step (wave-uniform)
+#define FL_I(n) std::integral_constant<int, n>{}
+#define FL_SB __builtin_amdgcn_sched_barrier(0)
+  auto step = [&](auto kyc, auto parc, int c) {
+    constexpr int KY = decltype(kyc)::value, PAR = decltype(parc)::value;  // PAR = c & 1
+    constexpr int KYN = (KY + 1) & 3, CN = (KY + 1) >> 2;                  // next step: row KYN of chunk c + CN
+    const int sln = sl == 2 ? 0 : sl + 1;
+    const char* Ah = smem + PAR * ABUF_B + KY * RPB;                       // this step's a_h (read inside the step)
+    const char* Aln = smem + ((PAR + CN) & 1) * ABUF_B + PLANE_B + KYN * RPB;
+    const char* Bn = smem + bfrag + sln * SLOT_B;
+    const int cs = c + 1 < nC ? c + 1 : c;                                 // the chunk being converted while chunk c runs
+    auto SLOT = [&](auto gp) {
+      constexpr int gi = decltype(gp)::value;
+      if constexpr (KY < 2) stage_slot(FL_I(48 * KY + gi), FL_I(1 - PAR), 1 - PAR, cs);
+      else if constexpr (KY == 3 && gi == 47)                              // next chunk's window: its first item's coefficient read
+        stage_slot(FL_I(-1), FL_I(PAR), PAR, c + 2 < nC ? c + 2 : (c + 1 < nC ? c + 1 : c));
+    };
+#define FL_MF(AA, BB, t)                                                                                             \
+    acc[(t) >> 2][(t) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AA[(t) >> 2], BB[(t) & 3], acc[(t) >> 2][(t) & 3], 0, 0, 0); FL_SB;
+#define FL_MS(AA, BB, t, gi) FL_MF(AA, BB, t) SLOT(FL_I(gi)); FL_SB;
+#define FL_MR(AA, BB, t, gi, dst, src)                                                                               \
+    FL_MF(AA, BB, t) dst = *reinterpret_cast<const f16x8_t*>(src); FL_SB; SLOT(FL_I(gi)); FL_SB;
+    // piece 1: a_l b_h; under it a_h of THIS step
+    FL_MF(al, bh, 0) FL_MF(al, bh, 1)
+    ah[0] = *reinterpret_cast<const f16x8_t*>(Ah + abase[0]); FL_SB; SLOT(FL_I(0)); FL_SB;
+    FL_MF(al, bh, 2)
+    ah[1] = *reinterpret_cast<const f16x8_t*>(Ah + abase[1]); FL_SB; SLOT(FL_I(1)); FL_SB;
+    FL_MF(al, bh, 3)
+    ah[2] = *reinterpret_cast<const f16x8_t*>(Ah + abase[2]); FL_SB; SLOT(FL_I(2)); FL_SB;
+    FL_MF(al, bh, 4)
+    ah[3] = *reinterpret_cast<const f16x8_t*>(Ah + abase[3]); FL_SB; SLOT(FL_I(3)); FL_SB;
+    FL_MS(al, bh, 5, 4) FL_MS(al, bh, 6, 5) FL_MS(al, bh, 7, 6) FL_MS(al, bh, 8, 7) FL_MS(al, bh, 9, 8) FL_MS(al, bh, 10, 9)
+    FL_MS(al, bh, 11, 10) FL_MS(al, bh, 12, 11) FL_MS(al, bh, 13, 12) FL_MS(al, bh, 14, 13) FL_MS(al, bh, 15, 14)
+    // piece 2: a_h b_l; under it a_l and b_h of the NEXT step
+    FL_MS(ah, bl, 0, 15) FL_MS(ah, bl, 1, 16)
+    FL_MR(ah, bl, 2, 17, al[0], Aln + abase[0]) FL_MR(ah, bl, 3, 18, al[1], Aln + abase[1])
+    FL_MR(ah, bl, 4, 19, al[2], Aln + abase[2]) FL_MR(ah, bl, 5, 20, al[3], Aln + abase[3])
+    FL_MR(ah, bl, 6, 21, bn[0], Bn) FL_MR(ah, bl, 7, 22, bn[1], Bn + 256)
+    FL_MR(ah, bl, 8, 23, bn[2], Bn + 2048) FL_MR(ah, bl, 9, 24, bn[3], Bn + 2048 + 256)
+    FL_MS(ah, bl, 10, 25) FL_MS(ah, bl, 11, 26) FL_MS(ah, bl, 12, 27) FL_MS(ah, bl, 13, 28) FL_MS(ah, bl, 14, 29) FL_MS(ah, bl, 15, 30)
+    // piece 3: a_h b_h; under it b_l of the next step, then the weight DMA three steps ahead (+ the halo loads in step 2 of an even chunk)
+    FL_MS(ah, bh, 0, 31) FL_MS(ah, bh, 1, 32)
+    FL_MR(ah, bh, 2, 33, bl[0], Bn + 1024) FL_MR(ah, bh, 3, 34, bl[1], Bn + 256 + 1024)
+    FL_MR(ah, bh, 4, 35, bl[2], Bn + 2048 + 1024) FL_MR(ah, bh, 5, 36, bl[3], Bn + 2048 + 256 + 1024)
+    FL_MS(ah, bh, 6, 37) FL_MS(ah, bh, 7, 38) FL_MS(ah, bh, 8, 39)
+    FL_MF(ah, bh, 9)
+    dma_step(c + ((KY + 3) >> 2), (KY + 3) & 3, sl);
+    if constexpr (KY == 2 && PAR == 0) stage_load(c + 2 < nC ? (c + 2) >> 1 : (nC - 1) >> 1);
+    FL_SB;
+    SLOT(FL_I(40)); FL_SB;
+    FL_MS(ah, bh, 10, 41) FL_MS(ah, bh, 11, 42) FL_MS(ah, bh, 12, 43) FL_MS(ah, bh, 13, 44) FL_MS(ah, bh, 14, 45) FL_MS(ah, bh, 15, 46)
+    SLOT(FL_I(47)); FL_SB;
+#undef FL_MR
+#undef FL_MS
+#undef FL_MF
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) bh[t4] = bn[t4];
+    sl = sln;
+    // vmcnt, oldest first at the end of step s: DMA(s+2), [halo loads of step s-1], DMA(s+3), [halo loads of step s]
+    if constexpr (KY == 2 && PAR == 0) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 + 2 * NST) : "memory");
+    } else if constexpr (KY == 3 && PAR == 0) {
+      FL_STAGE_WAIT4(2);
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    FL_SB;
+  };
+#pragma unroll 1
+  for (int c = 0; c < nC; c += 2) {
+    step(FL_I(0), FL_I(0), c); step(FL_I(1), FL_I(0), c); step(FL_I(2), FL_I(0), c); step(FL_I(3), FL_I(0), c);
+    step(FL_I(0), FL_I(1), c + 1); step(FL_I(1), FL_I(1), c + 1); step(FL_I(2), FL_I(1), c + 1); step(FL_I(3), FL_I(1), c + 1);
+  }
+#undef FL_I
+#undef FL_SB
+#undef FL_STAGE_WAIT4
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float st1[4], st2[4], bv[4];
+  const bool has_act = g.act != FL_ACT_NONE;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    st1[tn] = st2[tn] = 0.f;
+    bv[tn] = g.bias ? g.bias[tile_n0 + wc * 64 + tn * 16 + l16] : 0.f;
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = tile_m0 + wr * 64 + tm * 16 + 4 * kg + e;
+      float* yrow = g.y + (size_t)m * g.Cout + tile_n0 + wc * 64 + l16;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        float v = acc[tm][tn][e] * out_scale + bv[tn];
+        if (has_act) v = fl::apply_act(v, g.act, g.act_param);
+        yrow[tn * 16] = v;
+        st1[tn] += v;
+        st2[tn] += v * v;
+      }
+    }
+  }
+  h2p_stats_tail(g, st1, st2, tile_m0, tile_n0, wr, wc, l16, kg, smem);
+}
+
 // ---- weight pack: fp32 [N][K] -> header + [16-k group][32-col tile][piece h|l][lane][8 halfs]
 __global__ void h2_amax_kernel(const float* __restrict__ w, long long n, unsigned* hdr) {
   float m = 0.f;
@@ -1311,6 +1621,8 @@ void h2_set_attr() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2p_kernel<W, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2p_kernel<W, 0, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_h2p_kernel<W, 1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2p_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2p_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv4x4s2_h2_kernel<W, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
 }
@@ -1519,13 +1831,20 @@ static int h2_pre_bytes(int ksize, int Wout, int Cin, int bm = 256) {
 #define FL_H2_PAIRS 1  // 0: timing-only A/B build that keeps every 3x3 conv on the 32x32x16 kernel (tools/build_variant_lib.sh)
 #endif
 bool conv3x3_h2_pairs(int Cin) { return FL_H2_PAIRS && Cin % 64 == 0; }
+// the 4x4 convs run on their 16x16x32 kernel (same pack layout 1) wherever its 48 KB weight ring + the pre-op coefficients fit the LDS
+bool conv4x4s2_h2_pairs(int lds_bytes) { return FL_H2_PAIRS && lds_bytes <= 160 * 1024; }
 
 int conv_h2_lds_bytes(int ksize, int Win, int Cin, bool pre) {
   const int Wout = ksize == 3 ? Win : Win / 2;
   int base;
   if (ksize == 3 && conv3x3_h2_pairs(Cin)) base = Wout == 32 ? H2PGeom<32, 256>::LDS_B : (Wout == 16 ? H2PGeom<16, 256>::LDS_B : H2PGeom<8, 256>::LDS_B);
   else if (ksize == 3) base = Wout == 32 ? H2Geom<32>::LDS_B : (Wout == 16 ? H2Geom<16>::LDS_B : H2Geom<8>::LDS_B);
-  else base = Wout == 32 ? H2Geom4<32>::LDS_B : (Wout == 16 ? H2Geom4<16>::LDS_B : H2Geom4<8>::LDS_B);
+  else {
+    const int pb = pre ? h2_pre_bytes(ksize, Wout, Cin) : 0;
+    const int basep = Wout == 32 ? H2PGeom4<32>::LDS_B : (Wout == 16 ? H2PGeom4<16>::LDS_B : H2PGeom4<8>::LDS_B);
+    if (conv4x4s2_h2_pairs(basep + pb)) return basep + pb;  // the 16x16x32 kernel where it fits
+    base = Wout == 32 ? H2Geom4<32>::LDS_B : (Wout == 16 ? H2Geom4<16>::LDS_B : H2Geom4<8>::LDS_B);
+  }
   return base + (pre ? h2_pre_bytes(ksize, Wout, Cin) : 0);
 }
 
@@ -1581,8 +1900,13 @@ int launch_conv_h2(const float* x, const void* wpack, const float* bias, float* 
   } while (0)
 #define FL_LAUNCH4(WW)                                                                                               \
   do {                                                                                                             \
-    if (prio) hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 1>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B + pre_b, s, g);  \
-    else hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 0>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B + pre_b, s, g);       \
+    if (conv4x4s2_h2_pairs(H2PGeom4<WW>::LDS_B + pre_b)) {                                                         \
+      if (prio) hipLaunchKernelGGL((conv4x4s2_h2p_kernel<WW, 1>), dim3(blocks), dim3(512), H2PGeom4<WW>::LDS_B + pre_b, s, g);  \
+      else hipLaunchKernelGGL((conv4x4s2_h2p_kernel<WW, 0>), dim3(blocks), dim3(512), H2PGeom4<WW>::LDS_B + pre_b, s, g);       \
+    } else {                                                                                                       \
+      if (prio) hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 1>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B + pre_b, s, g);  \
+      else hipLaunchKernelGGL((conv4x4s2_h2_kernel<WW, 0>), dim3(blocks), dim3(512), H2Geom4<WW>::LDS_B + pre_b, s, g);       \
+    }                                                                                                              \
   } while (0)
   if (ksize == 3 && conv3x3_h2_pairs(Cin)) {
     if (W == 32) FL_LAUNCHP(32);
