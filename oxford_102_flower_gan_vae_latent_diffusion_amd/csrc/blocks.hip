@@ -201,9 +201,9 @@ int fl_res_tail_map(const float* y, const float* scale, const float* shift, cons
   if (npix == 0) return FL_OK;
   const int C4 = C / 4;
 #define LAUNCH_MAP(L) hipLaunchKernelGGL(res_tail_map_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, B, HW, C, s_per_image)
-  if (C4 >= 64) LAUNCH_MAP(64);
-  else if (C4 >= 32) LAUNCH_MAP(32);
-  else if (C4 >= 16) LAUNCH_MAP(16);
+  // lanes per pixel: 8 (C = 128: four float4 per lane in flight, three shuffle steps per reduction) or 16 - one lane per float4 and a
+  // five / six step shuffle tree per pixel pair made the pass shuffle-bound (3.6 TB/s on the 32x32x128 stage; its neighbour 5.2)
+  if (C4 >= 64) LAUNCH_MAP(16);
   else if (C4 >= 8) LAUNCH_MAP(8);
   else LAUNCH_MAP(1);
 #undef LAUNCH_MAP
