@@ -129,7 +129,8 @@ KERNEL_NAMES = {
               "power of two and split into 2 fp16 pieces, 3 x v_mfma_f32_16x16x32_f16 per 32 k (two taps x 16 channels), fp32 "
               "accumulation; input halo split once per 16-channel chunk at LDS staging with the producer's LayerNorm2d-apply + Swish "
               "fused in, pre-split weights through an LDS-DMA ring; conv3x3_h2_kernel = the 32x32x16 variant for Cin % 64 != 0)",
-    "h2_4x4": "conv4x4s2_h2_kernel<Wo,PRE> (4x4 s2 p1 down-sampling convs, same math; 16-wide k group = 2 taps x 8 channels)",
+    "h2_4x4": "conv4x4s2_h2p_kernel<Wo,PRE> (4x4 s2 p1 down-sampling convs, same math on v_mfma_f32_16x16x32_f16: a 32-wide k step = one "
+              "kernel row x 8 channels; conv4x4s2_h2_kernel = the 32x32x16 variant where the 48 KB weight ring does not fit)",
     "halo_3x3": "conv3x3_halo_kernel<W,TM> (r01 kernel, bf16x3 split math: 6 x v_mfma_f32_32x32x16_bf16 per 16 k)",
     "halo_4x4": "conv4x4s2_halo_kernel<Wo,TM> (r01 kernel, bf16x3 split math)",
     "gemm": "gemm_kernel<128,128,2,2,A_KC_CONV,..> (implicit-GEMM conv)",
