@@ -825,3 +825,37 @@ def test_attention_forward_onepass_vs_fp64(dev, shape):
         merged2, P2 = ops.attention_fwd(qd, nh, scale, want_p=True)
         close(merged2, ref, 2e-5)
         assert (P2.cpu().double() - P).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("B,C,H", [(64, 128, 32), (128, 256, 16), (256, 512, 8)])
+def test_f16x2_pair_kernels_on_full_256_pixel_tiles(dev, B, C, H):
+    """The headline configuration's 3x3 kernels - `conv3x3_h2p_kernel<W, PRE, 256>`, 256-pixel tiles on >= 256 tiles (the small cases
+    above run its 128-pixel variant) - with and without the fused LayerNorm2d-apply + Swish pre-op, against the native fp32-MFMA
+    implicit-GEMM kernel on the WHOLE tensor (5e-6 of the output's max: each side is <= 3e-6 from fp64 at K = 4608) and its fused LayerNorm2d statistics
+    (finished in-kernel for the 16 / 8-wide maps, by the finalize launch for the 32-wide one) against the reference path's."""
+    g = torch.Generator().manual_seed(B + C)
+    x = torch.randn(B, H, H, C, generator=g)
+    x = (x * torch.sigmoid(x)).to(dev)
+    w = (torch.randn(C, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).to(dev)
+    b = (torch.randn(C, generator=g) * 0.1).to(dev)
+    lnw, lnb = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.2).to(dev)
+    wh2, geom = ops.pack_weight_f16x2(w), tuple(w.shape)
+    assert (B * H * H // 256) * (C // 128) >= 256
+    amax = (x.abs().max() * 1.25).reshape(1)
+    old = ops.get_gemm_math()
+    ops.set_gemm_math("fp32")
+    y32, (sc32, sh32, _, _) = ops.conv2d_fwd_instnorm(x, w, b, 1, 1, lnw, lnb, 1e-5)
+    ops.set_gemm_math(old)
+    y, (sc, sh, _, _) = ops.conv2d_fwd_f16x2(x, wh2, geom, b, 1, 1, ln_w=lnw, ln_b=lnb, x_amax=amax)
+    scale = y32.abs().max().item()
+    assert (y - y32).abs().max().item() <= 5e-6 * scale
+    assert (sc - sc32).abs().max().item() <= 1e-5 * sc32.abs().max().item()
+    assert (sh - sh32).abs().max().item() <= 2e-5 * max(1.0, sh32.abs().max().item())
+    # fused pre-op: conv(swish(x * s + t)) == conv of the materialised activation
+    ps, pt = (torch.rand(B, C, generator=g) + 0.5).to(dev), (torch.randn(B, C, generator=g) * 0.3).to(dev)
+    xa = ops.affine_act(x, ps, pt, act=ops.ACT_SWISH)
+    bnd = (xa.abs().max() * 1.25).reshape(1)
+    ya = ops.conv2d_fwd_f16x2(xa, wh2, geom, b, 1, 1, x_amax=bnd)
+    yp = ops.conv2d_fwd_f16x2(x, wh2, geom, b, 1, 1, x_amax=bnd, pre=(ps, pt))
+    assert (yp - ya).abs().max().item() <= 4e-6 * ya.abs().max().item()   # (the conv-side Swish uses v_exp / v_rcp: a few ulp)
+    assert torch.isfinite(yp).all()
