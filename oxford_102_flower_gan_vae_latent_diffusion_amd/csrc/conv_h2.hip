@@ -639,14 +639,6 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2p_kernel(const H2Args g)
     vmask |= (ok ? 1u : 0u) << j;
   }
   float* ss = reinterpret_cast<float*>(smem + G::LDS_B);
-  if constexpr (PRE) {
-    for (int i = tid; i < NI * Cin; i += NT) {
-      const int nl = i / Cin, ch = i - nl * Cin;
-      ss[i] = g.pre_scale[(size_t)(img0 + nl) * Cin + ch];
-      ss[NI * Cin + i] = g.pre_shift[(size_t)(img0 + nl) * Cin + ch];
-    }
-    __syncthreads();
-  }
 
   f32x4v stg[NST];
   auto stage_load = [&](int c) {
@@ -769,6 +761,16 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2p_kernel(const H2Args g)
   dma_pair(0, 0);
   dma_pair(1, 1);
   dma_pair(2, 2);
+  // the pre-op coefficients of the tile's images come in BEHIND the first halo loads and weight pieces (in front of them they cost
+  // every tile one global round trip before its first load was even requested)
+  if constexpr (PRE) {
+    for (int i = tid; i < NI * Cin; i += NT) {
+      const int nl = i / Cin, ch = i - nl * Cin;
+      ss[i] = g.pre_scale[(size_t)(img0 + nl) * Cin + ch];
+      ss[NI * Cin + i] = g.pre_shift[(size_t)(img0 + nl) * Cin + ch];
+    }
+    __syncthreads();
+  }
   FL_STAGE_WAIT(3 * PPW);
   stage_item(std::integral_constant<int, 0>{}, 0, 0);
   stage_item(std::integral_constant<int, 1>{}, 0, 0);
@@ -1290,14 +1292,6 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2p_kernel(const H2Args g) {
     vmask |= (ok ? 1u : 0u) << j;
   }
   float* ss = reinterpret_cast<float*>(smem + G::LDS_B);
-  if constexpr (PRE) {
-    for (int i = tid; i < NI * Cin; i += NT) {
-      const int nl = i / Cin, ch = i - nl * Cin;
-      ss[i] = g.pre_scale[(size_t)(img0 + nl) * Cin + ch];
-      ss[NI * Cin + i] = g.pre_shift[(size_t)(img0 + nl) * Cin + ch];
-    }
-    __syncthreads();
-  }
 
   f32x4v stg[2][NST];  // [half of the chunk pair][item]
   auto stage_load = [&](int sc) {
@@ -1416,6 +1410,16 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2p_kernel(const H2Args g) {
   dma_step(0, 0, 0);
   dma_step(0, 1, 1);
   dma_step(0, 2, 2);
+  // the pre-op coefficients of the tile's images come in BEHIND the first halo loads and weight pieces (in front of them they cost
+  // every tile one global round trip before its first load was even requested)
+  if constexpr (PRE) {
+    for (int i = tid; i < NI * Cin; i += NT) {
+      const int nl = i / Cin, ch = i - nl * Cin;
+      ss[i] = g.pre_scale[(size_t)(img0 + nl) * Cin + ch];
+      ss[NI * Cin + i] = g.pre_shift[(size_t)(img0 + nl) * Cin + ch];
+    }
+    __syncthreads();
+  }
   FL_STAGE_WAIT4(6);
   stage_store(0, 0);
   stage_slot(std::integral_constant<int, -1>{}, std::integral_constant<int, 1>{}, 1, nC > 1 ? 1 : 0);  // (the first window's coefficient reads)
