@@ -349,8 +349,9 @@ def _cpu_time(fn, iters, warm):
 
 def cpu_baseline(threads, quick=False):
     """The CPU oracle (validated restatement of the reference's code path, same torch-CPU ops) timed on
-    this box's host cores on BOUNDED samples of configs 1, 2, 3 and 5: >= 3 warm-up and >= 10 timed iterations each, median
-    and min. Checker code: imported only here. The top-level value is config 3's (the headline workload)."""
+    this box's host cores on BOUNDED samples of configs 1, 2, 3 and 5 (median and min): config 3 - the headline workload and the
+    top-level value - at the metric's own batch of 256 (6 timed + 1 warm-up step), the others on >= 3 warm-up and >= 10 timed
+    iterations of smaller batches. Checker code: imported only here."""
     from oracle import procedural_init as pinit
     from oracle import v2_oracle as O
     shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_shapes.json")))
@@ -360,12 +361,14 @@ def cpu_baseline(threads, quick=False):
     g = torch.Generator().manual_seed(0)
     per = {}
     it, wm = (3, 1) if quick else (10, 3)
-    # config 3: the latent-DDPM step (frozen encoder fwd + U-Net fwd/bwd + clip + AdamW), batch 32
-    B = 32
+    # config 3: the latent-DDPM step (frozen encoder fwd + U-Net fwd/bwd + clip + AdamW) at the metric's own batch of 256
+    # (~1.7 s per step on 16 threads: 6 timed + 1 warm-up step, ~12 s)
+    B = 256
+    it3, wm3 = (2, 1) if quick else (6, 1)
     data, labels = torch.rand(B, 3, 64, 64, generator=g), torch.randint(0, 102, (B,), generator=g)
     re, t, eps = torch.randn(B, 256, generator=g), torch.randint(0, 1000, (B,), generator=g), torch.randn(B, 256, generator=g)
-    med, mn = _cpu_time(lambda: O.ddpm_step(ae_sd, un_sd, data, labels, re, t, eps), it, wm)
-    per["config3_ddpm_step"] = {"value": B / med, "unit": "images/s", "batch": B, "iters": it, "median_s": med, "min_s": mn}
+    med, mn = _cpu_time(lambda: O.ddpm_step(ae_sd, un_sd, data, labels, re, t, eps), it3, wm3)
+    per["config3_ddpm_step"] = {"value": B / med, "unit": "images/s", "batch": B, "iters": it3, "median_s": med, "min_s": mn}
     # config 1: VAE recon-only train step (AE fwd + bwd + clip + AdamW), batch 8
     B1 = 8
     d1, e1 = torch.rand(B1, 3, 64, 64, generator=g), torch.randn(B1, 256, generator=g)
@@ -403,7 +406,7 @@ def cpu_baseline(threads, quick=False):
     top = per["config3_ddpm_step"]
     return dict(value=top["value"], unit="images/s", cores=threads, kind="port",
                 sample="%d timed + %d warm-up steps of the v2 latent-DDPM step at batch %d (oracle.ddpm_step, fp32, torch %s); median"
-                       % (it, wm, B, torch.__version__),
+                       % (it3, wm3, B, torch.__version__),
                 cpu_model=_cpu_model(),
                 cores_visible=len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
                 cores_note="threads = min(16, visible): one GPU's share of the host, as the GPU box allots it",
