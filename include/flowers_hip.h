@@ -260,7 +260,10 @@ int fl_attention_fwd(const float* qkv, float* out, float* P, float* stats, int B
 /* stats optional (B,heads,HW,2): per query the max of scale*s and the sum of exp - all the backward needs to recompute P.
  * Backward of the same core (v2:446-457) in two launches, no (HW x HW) tensor in HBM, no atomics: a dQ kernel (one wave = 32
  * queries) and a dK / dV kernel (one wave = 32 keys), both recomputing the probabilities from Q, K and `stats`; merged / dmerged
- * in the forward's d-major channel order, dqkv in the qkv layout (every element written). Workspace: B*heads*HW floats. */
+ * in the forward's d-major channel order, dqkv in the qkv layout (every element written). Workspace: B*heads*HW floats.
+ * With d % 4 == 0, HW % 64 == 0 and 16-byte aligned qkv / dqkv both run as LDS-staged v_mfma_f32_16x16x4_f32 kernels (K, V, Q,
+ * dO and their transposes staged once per block; every accumulator tile is the next contraction's B operand as it stands);
+ * otherwise (HW % 32 == 0) the 32x32x2 kernels with operands from global memory. d <= 32. */
 size_t fl_attention_bwd_workspace_bytes(int B, int HW, int heads);
 int fl_attention_bwd(const float* qkv, const float* merged, const float* dmerged, const float* stats, float* dqkv, int B, int HW,
                      int C, int heads, float scale, void* ws, size_t ws_bytes, fl_stream_t stream);

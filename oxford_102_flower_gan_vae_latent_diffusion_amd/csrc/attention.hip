@@ -394,6 +394,249 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- backward, LDS-staged
+// The two backward kernels rebuilt like attention_fwd_onepass_kernel: v_mfma_f32_16x16x4_f32, every operand a ds_read_b128 out
+// of LDS images staged once per block (row-major images with a 4-float pad: conflict-free; the transposed ones [dim][256 + 4]),
+// exp2 on the transcendental pipe, and every accumulator tile used AS IT STANDS as the B operand of the next contraction.
+//   dQ kernel (a lane = a query, 8 waves x 32 queries of one (image, head), keys through LDS in chunks of 256):
+//     S^T = K Q^T,  P = exp2(s' - m') / l,  dP^T = V dO^T,  dS^T = scale P (dP^T - D),  dQ^T += K^T dS^T;  also writes D = <dO, O>
+//   dK / dV kernel (a lane = a key, queries through LDS):
+//     S = Q K^T,  P,  dP = dO V^T,  dS;  dV^T += dO^T P,  dK^T += Q^T dS
+template <int DH>
+__global__ __launch_bounds__(512, 2) void attention_bwd_dq_lds_kernel(const AttnBwdArgs g) {
+  constexpr int KC = 256, NJ = DH / 16, PR = DH + 4, PT = KC + 4, KT = 2;
+  typedef float f32x4a __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float at_smem[];
+  float* Ks = at_smem;              // [key][PR]
+  float* Vs = Ks + KC * PR;         // [key][PR]
+  float* Kt = Vs + KC * PR;         // [dim][PT]
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, g4 = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z, nh = g.nh;
+  const int q0 = blockIdx.x * 256 + 32 * w;
+  const bool active = q0 < g.HW;
+  const int C3 = 3 * g.C, d = g.d;
+  const float* base = g.qkv + (size_t)b * g.HW * C3 + h * d;
+  const float qs = g.scale * 1.4426950408889634f;
+
+  f32x4a qf[2][NJ], dof[2][NJ], dq[2][NJ];
+  float mq[2], il[2], Dq[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = q0 + 16 * qt + ln;
+    float part = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int dim = 16 * jj + 4 * g4;
+      f32x4a v = {0.f, 0.f, 0.f, 0.f}, go = {0.f, 0.f, 0.f, 0.f};
+      if (active && dim < d) {
+        v = *reinterpret_cast<const f32x4a*>(base + (size_t)q * C3 + dim);
+        const float* dOr = g.dmerged + ((size_t)b * g.HW + q) * g.C + h;
+        const float* Or = g.merged + ((size_t)b * g.HW + q) * g.C + h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          go[e] = dOr[(size_t)(dim + e) * nh];
+          part += go[e] * Or[(size_t)(dim + e) * nh];
+        }
+      }
+      qf[qt][jj] = v * qs;
+      dof[qt][jj] = go;
+      dq[qt][jj] = f32x4a{0.f, 0.f, 0.f, 0.f};
+    }
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    Dq[qt] = part;
+    mq[qt] = 0.f;
+    il[qt] = 0.f;
+    if (active) {
+      const float* st = g.stats + (((size_t)b * nh + h) * g.HW + q) * 2;
+      mq[qt] = st[0] * 1.4426950408889634f;
+      il[qt] = 1.0f / st[1];
+      if (g4 == 0) g.D[((size_t)b * nh + h) * g.HW + q] = part;
+    }
+  }
+
+  for (int kc = 0; kc < g.HW; kc += KC) {
+    const int nk = g.HW - kc < KC ? g.HW - kc : KC;
+    __syncthreads();
+    for (int idx = tid; idx < nk * (DH / 4); idx += 512) {
+      const int key = idx / (DH / 4), c4 = idx - key * (DH / 4);
+      f32x4a kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (4 * c4 < d) {
+        const float* src = base + (size_t)(kc + key) * C3 + 4 * c4;
+        kv = *reinterpret_cast<const f32x4a*>(src + g.C);
+        vv = *reinterpret_cast<const f32x4a*>(src + 2 * g.C);
+      }
+      *reinterpret_cast<f32x4a*>(Ks + key * PR + 4 * c4) = kv;
+      *reinterpret_cast<f32x4a*>(Vs + key * PR + 4 * c4) = vv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Kt[(4 * c4 + e) * PT + key] = kv[e];
+    }
+    __syncthreads();
+    if (!active) continue;
+    for (int kg = 0; kg < nk; kg += 16 * KT) {
+      f32x4a kf[KT][NJ], vf[KT][NJ], tf[KT][NJ];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+          kf[kt][jj] = *reinterpret_cast<const f32x4a*>(Ks + (kg + 16 * kt + ln) * PR + 16 * jj + 4 * g4);
+          vf[kt][jj] = *reinterpret_cast<const f32x4a*>(Vs + (kg + 16 * kt + ln) * PR + 16 * jj + 4 * g4);
+          tf[kt][jj] = *reinterpret_cast<const f32x4a*>(Kt + (16 * jj + ln) * PT + kg + 16 * kt + 4 * g4);
+        }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          f32x4a sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][jj][e], qf[qt][jj][e], sc, 0, 0, 0);
+              dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][jj][e], dof[qt][jj][e], dp, 0, 0, 0);
+            }
+          f32x4a ds;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(sc[r] - mq[qt]) * il[qt] * (dp[r] - Dq[qt]) * g.scale;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < NJ; ++mt) dq[qt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[kt][mt][r], ds[r], dq[qt][mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float* dQ = g.dqkv + ((size_t)b * g.HW + q0 + 16 * qt + ln) * C3 + h * d;
+#pragma unroll
+    for (int mt = 0; mt < NJ; ++mt) {
+      const int i = 16 * mt + 4 * g4;
+      if (i < d) *reinterpret_cast<f32x4a*>(dQ + i) = dq[qt][mt];  // d % 4 == 0: a lane's four rows exist together
+    }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(512, 2) void attention_bwd_dkv_lds_kernel(const AttnBwdArgs g) {
+  constexpr int QC = 256, NJ = DH / 16, PR = DH + 4, PT = QC + 4;
+  typedef float f32x4a __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float at_smem[];
+  float* Qs = at_smem;               // [query][PR], scaled by scale * log2(e)
+  float* Gs = Qs + QC * PR;          // dO [query][PR]
+  float* Qt = Gs + QC * PR;          // Q^T [dim][PT] (unscaled)
+  float* Gt = Qt + DH * PT;          // dO^T [dim][PT]
+  float* Ms = Gt + DH * PT;          // m' | 1 / l | D, 256 each
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, g4 = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z, nh = g.nh;
+  const int k0 = blockIdx.x * 256 + 32 * w;
+  const bool active = k0 < g.HW;
+  const int C3 = 3 * g.C, d = g.d;
+  const float* base = g.qkv + (size_t)b * g.HW * C3 + h * d;
+  const float qs = g.scale * 1.4426950408889634f;
+
+  f32x4a kf[2][NJ], vf[2][NJ], dk[2][NJ], dv[2][NJ];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int dim = 16 * jj + 4 * g4;
+      f32x4a kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (active && dim < d) {
+        const float* src = base + (size_t)(k0 + 16 * kt + ln) * C3 + dim;
+        kv = *reinterpret_cast<const f32x4a*>(src + g.C);
+        vv = *reinterpret_cast<const f32x4a*>(src + 2 * g.C);
+      }
+      kf[kt][jj] = kv;
+      vf[kt][jj] = vv;
+      dk[kt][jj] = f32x4a{0.f, 0.f, 0.f, 0.f};
+      dv[kt][jj] = f32x4a{0.f, 0.f, 0.f, 0.f};
+    }
+
+  for (int qc = 0; qc < g.HW; qc += QC) {
+    const int nq = g.HW - qc < QC ? g.HW - qc : QC;
+    __syncthreads();
+    for (int idx = tid; idx < nq * (DH / 4); idx += 512) {
+      const int q = idx / (DH / 4), c4 = idx - q * (DH / 4);
+      f32x4a qv = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+      if (4 * c4 < d) {
+        qv = *reinterpret_cast<const f32x4a*>(base + (size_t)(qc + q) * C3 + 4 * c4);
+        const float* dOr = g.dmerged + ((size_t)b * g.HW + qc + q) * g.C + h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[e] = dOr[(size_t)(4 * c4 + e) * nh];
+      }
+      *reinterpret_cast<f32x4a*>(Qs + q * PR + 4 * c4) = qv * qs;
+      *reinterpret_cast<f32x4a*>(Gs + q * PR + 4 * c4) = gv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Qt[(4 * c4 + e) * PT + q] = qv[e];
+        Gt[(4 * c4 + e) * PT + q] = gv[e];
+      }
+    }
+    for (int q = tid; q < nq; q += 512) {
+      const float* st = g.stats + (((size_t)b * nh + h) * g.HW + qc + q) * 2;
+      Ms[q] = st[0] * 1.4426950408889634f;
+      Ms[256 + q] = 1.0f / st[1];
+      Ms[512 + q] = g.D[((size_t)b * nh + h) * g.HW + qc + q];
+    }
+    __syncthreads();
+    if (!active) continue;
+    for (int qb = 0; qb < nq; qb += 16) {
+      f32x4a qa[NJ], ga[NJ], qtf[NJ], gtf[NJ];
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        qa[jj] = *reinterpret_cast<const f32x4a*>(Qs + (qb + ln) * PR + 16 * jj + 4 * g4);
+        ga[jj] = *reinterpret_cast<const f32x4a*>(Gs + (qb + ln) * PR + 16 * jj + 4 * g4);
+        qtf[jj] = *reinterpret_cast<const f32x4a*>(Qt + (16 * jj + ln) * PT + qb + 4 * g4);
+        gtf[jj] = *reinterpret_cast<const f32x4a*>(Gt + (16 * jj + ln) * PT + qb + 4 * g4);
+      }
+      const f32x4a m4 = *reinterpret_cast<const f32x4a*>(Ms + qb + 4 * g4);          // statistics of queries 4 g4 + r
+      const f32x4a l4 = *reinterpret_cast<const f32x4a*>(Ms + 256 + qb + 4 * g4);
+      const f32x4a D4 = *reinterpret_cast<const f32x4a*>(Ms + 512 + qb + 4 * g4);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x4a sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};   // [query 4 g4 + r][key ln]
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[jj][e], kf[kt][jj][e], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[jj][e], vf[kt][jj][e], dp, 0, 0, 0);
+          }
+        f32x4a pp, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pp[r] = __builtin_amdgcn_exp2f(sc[r] - m4[r]) * l4[r];
+          ds[r] = pp[r] * (dp[r] - D4[r]) * g.scale;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int mt = 0; mt < NJ; ++mt) {
+            dv[kt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gtf[mt][r], pp[r], dv[kt][mt], 0, 0, 0);
+            dk[kt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qtf[mt][r], ds[r], dk[kt][mt], 0, 0, 0);
+          }
+      }
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    float* dK = g.dqkv + ((size_t)b * g.HW + k0 + 16 * kt + ln) * C3 + g.C + h * d;
+#pragma unroll
+    for (int mt = 0; mt < NJ; ++mt) {
+      const int i = 16 * mt + 4 * g4;
+      if (i < d) {
+        *reinterpret_cast<f32x4a*>(dK + i) = dk[kt][mt];
+        *reinterpret_cast<f32x4a*>(dK + g.C + i) = dv[kt][mt];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -444,8 +687,27 @@ int fl_attention_bwd(const float* qkv, const float* merged, const float* dmerged
   AttnBwdArgs g;
   g.qkv = qkv; g.dmerged = dmerged; g.merged = merged; g.stats = stats; g.dqkv = dqkv; g.D = reinterpret_cast<float*>(ws);
   g.B = B; g.HW = HW; g.C = C; g.nh = heads; g.d = C / heads; g.scale = scale;
-  dim3 grid((unsigned)fl::cdiv(HW, 128), (unsigned)heads, (unsigned)B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (g.d % 4 == 0 && HW % 64 == 0 && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dqkv)) & 15) == 0) {
+    // LDS-staged 16x16x4 kernels (the same contractions; what the shape rules of the one-pass forward allow)
+    dim3 grid1((unsigned)fl::cdiv(HW, 256), (unsigned)heads, (unsigned)B);
+    const int DH = g.d <= 16 ? 16 : 32;
+    const size_t lds_q = (size_t)(2 * 256 * (DH + 4) + DH * 260) * sizeof(float);
+    const size_t lds_k = (size_t)(2 * 256 * (DH + 4) + 2 * DH * 260 + 768) * sizeof(float);
+    static bool attr = (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dq_lds_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dkv_lds_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dkv_lds_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)attr;
+    if (DH == 16) {
+      hipLaunchKernelGGL(attention_bwd_dq_lds_kernel<16>, grid1, dim3(512), lds_q, s, g);
+      hipLaunchKernelGGL(attention_bwd_dkv_lds_kernel<16>, grid1, dim3(512), lds_k, s, g);
+    } else {
+      hipLaunchKernelGGL(attention_bwd_dq_lds_kernel<32>, grid1, dim3(512), lds_q, s, g);
+      hipLaunchKernelGGL(attention_bwd_dkv_lds_kernel<32>, grid1, dim3(512), lds_k, s, g);
+    }
+    return fl::check_launch("attention_bwd_lds_kernels");
+  }
+  dim3 grid((unsigned)fl::cdiv(HW, 128), (unsigned)heads, (unsigned)B);
   if (g.d <= 16) {
     hipLaunchKernelGGL(attention_bwd_dq_kernel<16>, grid, dim3(256), 0, s, g);
     hipLaunchKernelGGL(attention_bwd_dkv_kernel<16>, grid, dim3(256), 0, s, g);

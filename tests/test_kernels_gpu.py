@@ -776,10 +776,13 @@ def test_f16x2_linear_long_reduction(dev, M, N, K, nb):
     assert not ops.linear_f16x2_ok(100, N, K) and not ops.linear_f16x2_ok(M, 96, K)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 8, 64, 4), (3, 16, 16, 128, 8), (1, 8, 4, 96, 4)])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64, 4), (3, 16, 16, 128, 8), (1, 8, 4, 96, 4), (2, 16, 16, 128, 4), (1, 16, 16, 96, 4),
+                                   (1, 32, 16, 64, 2)])
 def test_fused_attention_backward_vs_autograd(dev, shape):
     """fl_attention_bwd (dQ kernel + dK / dV kernel, probabilities recomputed from the forward's row statistics, no HW x HW tensor
-    in HBM) against torch fp64 autograd of softmax(scale Q K^T) V with the d-major head merge of v2:456-457; head dims 16, 16, 24."""
+    in HBM) against torch fp64 autograd of softmax(scale Q K^T) V with the d-major head merge of v2:456-457; head dims 16, 16, 24,
+    32, 24, 32: the LDS-staged 16x16x4 kernels (HW % 64 == 0; 512 tokens = two LDS chunks) and the round-3a kernels they fall
+    back to (HW = 32)."""
     B, H, W, C, nh = shape
     HW, d = H * W, C // nh
     g = torch.Generator().manual_seed(B * 100 + C)
