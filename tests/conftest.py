@@ -19,3 +19,22 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _quiesce_between_gpu_tests(request):
+    """GPU tests leave hipGraphs, private graph pools and persistent-program objects behind as (cyclic) garbage. Collect it and
+    drain the device BETWEEN tests - while nothing is in flight or being captured - instead of at whatever allocation inside the next
+    test the cyclic collector happens to run (one full-suite run of round 3 aborted inside the two-stream pipelined-trainer test, which
+    passes alone: DESIGN section 7c)."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import gc
+
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()
