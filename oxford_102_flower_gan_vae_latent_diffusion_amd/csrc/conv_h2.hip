@@ -519,8 +519,11 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
     chunk(std::integral_constant<int, 0>{}, c);
     chunk(std::integral_constant<int, 1>{}, c + 1);
   }
+  // Drain. The last period requested one more (clamped) set of halo loads that nothing consumes: the wait NAMES the staging
+  // registers, so that the compiler keeps them allocated until the loads have landed (with a bare s_waitcnt it moved epilogue
+  // index arithmetic into one of them above the wait, and a load that landed late overwrote it: DESIGN 7c)
+  FL_STAGE_WAIT(0);  // (and no LDS-DMA may outlive the block's LDS allocation)
 #undef FL_STAGE_WAIT
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the block's LDS allocation
 
   // ---- epilogue (C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
   float st1[2], st2[2], bv[2];
@@ -876,8 +879,11 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2p_kernel(const H2Args g)
   }
 #undef FL_I
 #undef FL_SB
+  // Drain. The last period requested one more (clamped) set of halo loads that nothing consumes: the wait NAMES the staging
+  // registers, so that the compiler keeps them allocated until the loads have landed (with a bare s_waitcnt it moved epilogue
+  // index arithmetic into one of them above the wait, and a load that landed late overwrote it: DESIGN 7c)
+  FL_STAGE_WAIT(0);  // (and no LDS-DMA may outlive the block's LDS allocation)
 #undef FL_STAGE_WAIT
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the block's LDS allocation
 
   // ---- epilogue (C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg)
   float st1[4], st2[4], bv[4];
@@ -1202,8 +1208,11 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
     chunk(std::integral_constant<int, 0>{}, c);
     chunk(std::integral_constant<int, 1>{}, c + 1);
   }
+  // Drain. The last period requested one more (clamped) set of halo loads that nothing consumes: the wait NAMES the staging
+  // registers, so that the compiler keeps them allocated until the loads have landed (with a bare s_waitcnt it moved epilogue
+  // index arithmetic into one of them above the wait, and a load that landed late overwrote it: DESIGN 7c)
+  FL_STAGE_WAIT4(0);
 #undef FL_STAGE_WAIT4
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   float st1[2], st2[2], bv[2];
   const bool has_act = g.act != FL_ACT_NONE;
@@ -1514,8 +1523,11 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2p_kernel(const H2Args g) {
   }
 #undef FL_I
 #undef FL_SB
+  // Drain. The last period requested one more (clamped) set of halo loads that nothing consumes: the wait NAMES the staging
+  // registers, so that the compiler keeps them allocated until the loads have landed (with a bare s_waitcnt it moved epilogue
+  // index arithmetic into one of them above the wait, and a load that landed late overwrote it: DESIGN 7c)
+  FL_STAGE_WAIT4(0);
 #undef FL_STAGE_WAIT4
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   float st1[4], st2[4], bv[4];
   const bool has_act = g.act != FL_ACT_NONE;
@@ -1836,7 +1848,10 @@ static int h2_pre_bytes(int ksize, int Wout, int Cin, int bm = 256) {
 #endif
 bool conv3x3_h2_pairs(int Cin) { return FL_H2_PAIRS && Cin % 64 == 0; }
 // the 4x4 convs run on their 16x16x32 kernel (same pack layout 1) wherever its 48 KB weight ring + the pre-op coefficients fit the LDS
-bool conv4x4s2_h2_pairs(int lds_bytes) { return FL_H2_PAIRS && lds_bytes <= 160 * 1024; }
+#ifndef FL_H2_PAIRS4
+#define FL_H2_PAIRS4 FL_H2_PAIRS
+#endif
+bool conv4x4s2_h2_pairs(int lds_bytes) { return FL_H2_PAIRS4 && lds_bytes <= 160 * 1024; }
 
 int conv_h2_lds_bytes(int ksize, int Win, int Cin, bool pre) {
   const int Wout = ksize == 3 ? Win : Win / 2;
