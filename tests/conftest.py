@@ -25,8 +25,8 @@ def dev():
 def _quiesce_between_gpu_tests(request):
     """GPU tests leave hipGraphs, private graph pools and persistent-program objects behind as (cyclic) garbage. Collect it and
     drain the device BETWEEN tests - while nothing is in flight or being captured - instead of at whatever allocation inside the next
-    test the cyclic collector happens to run (one full-suite run of round 3 aborted inside the two-stream pipelined-trainer test, which
-    passes alone: DESIGN section 7c)."""
+    test the cyclic collector happens to run (hygiene; put in while round 3's two-stream fault was hunted - its cause turned out to be
+    a kernel race, DESIGN section 7c - and kept: it costs a second over the suite)."""
     yield
     if request.node.get_closest_marker("gpu") is None:
         return

@@ -207,9 +207,9 @@ def test_sampler_graph_equals_eager_and_oracle(dev, unet):
 
 def test_pipelined_trainer_equals_plain_trainer(dev):
     """encoder(k+1) || denoiser-update(k) on two streams must give exactly the plain step's parameters. Runs in a process of its own
-    (like the data-parallel tests): the two-stream mode is the one path whose process has died twice inside a long pytest session
-    (an abort with no GPU-fault line, box- and timing-dependent, not reproduced in isolation) - a death there must
-    fail THIS test, not take the rest of the suite with it."""
+    (like the data-parallel tests): this is the test that exposed round 3's late-landing halo load (fixed; the
+    load of a second queue on the memory system is what made it show) - a GPU fault on this path must fail THIS test, not take the
+    rest of the suite with it. tools/pipe_fault_repro.py runs the same body without pytest (for a debugger)."""
     import torch.multiprocessing as mp
     mp.spawn(_pipelined_trainer_body, args=(), nprocs=1, join=True)
 
