@@ -487,6 +487,66 @@ def disc_bwd(dm, S, dp, need_wgrad=True, need_dx=True):
     return G, dx
 
 
+def disc_fwd_pair(dm, xa, xb, sync=None, world=1):
+    """The discriminator update's two passes (v2:1097-1098: D(real), D(fake.detach())) as ONE batch-stacked pass: every conv, the
+    final linear and the activations run once on [xa | xb]; BatchNorm keeps per-pass statistics (ops.batchnorm_stats_pair: each half
+    normalised by its own batch statistics, running buffers updated real-then-fake as two passes do), and under data parallelism
+    the two passes' SyncBatchNorm sums share one all-reduce per layer. Training mode only. -> (p_a, p_b), tape for disc_bwd_pair."""
+    assert dm.training, "disc_fwd_pair is the training-mode discriminator update"
+    pk = dm._pk
+    m = dm.model
+    B = xa.shape[0]
+    S = RBSaved()
+    S.B = B
+    S.x4 = ops.nchw_to_nhwc(torch.cat((xa, xb), 0), 4)
+    S.y0 = ops.conv2d_fwd(S.x4, pk.conv(m[0]), _d(m[0].bias), 2, 1, act=LRELU, act_param=0.2)
+    h = S.y0
+    S.blocks = []
+    S.sync, S.world = sync, world
+    for ci, bi in ((2, 3), (5, 6), (8, 9)):
+        conv, bn = m[ci], m[bi]
+        hin = h
+        yc = ops.conv2d_fwd(hin, pk.conv(conv), _d(conv.bias), 2, 1)
+        nba, nbb = ops.batchnorm_stats_pair(yc, _d(bn.weight), _d(bn.bias), bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                            sync=sync, world=world)
+        bn.num_batches_tracked += 2
+        h = torch.empty_like(yc)
+        ops.affine_act(yc[:B], nba[0], nba[1], act=LRELU, act_param=0.2, out=h[:B])
+        ops.affine_act(yc[B:], nbb[0], nbb[1], act=LRELU, act_param=0.2, out=h[B:])
+        S.blocks.append((hin, yc, nba, nbb))
+    S.hf = h.view(2 * B, -1)
+    S.wf = pk.conv(m[11]).view(1, -1)
+    S.logit = ops.linear(S.hf, S.wf, _d(m[11].bias))
+    p = ops.act_fwd(S.logit, SIG).view(-1)
+    return (p[:B], p[B:]), S
+
+
+def disc_bwd_pair(dm, S, dpa, dpb):
+    """Weight gradients of both passes of disc_fwd_pair, SUMMED (what set_grads(real) + add_grads(fake) accumulated): the weight-
+    gradient GEMMs contract over the stacked batch, the BatchNorm backward works per half (one exchange for both under `sync`)."""
+    pk = dm._pk
+    m = dm.model
+    B = S.B
+    G = {}
+    dp = torch.cat((_f32c(dpa).view(-1), _f32c(dpb).view(-1)), 0).view(-1, 1)
+    dlogit = ops.act_bwd(dp, S.logit, SIG)
+    G["model.11.weight"] = ops.unpack_conv_weight(ops.linear_wgrad(dlogit, S.hf).view(1, 4, 4, 512), 1, 512, 4, 4)
+    G["model.11.bias"] = ops.colsum(dlogit)
+    dh = ops.linear_dgrad(dlogit, S.wf).view(-1, 4, 4, 512)
+    for (ci, bi), (hin, yc, nba, nbb) in zip(((8, 9), (5, 6), (2, 3)), reversed(S.blocks)):
+        conv, bn = m[ci], m[bi]
+        dyc, dw, db = ops.batchnorm_bwd_pair(dh, yc, nba, nbb, _d(bn.weight), act=LRELU, act_param=0.2, sync=S.sync, world=S.world)
+        Co, Cin = conv.weight.shape[0], conv.weight.shape[1]
+        G["model.%d.weight" % bi], G["model.%d.bias" % bi] = dw, db
+        G["model.%d.weight" % ci] = ops.unpack_conv_weight(ops.conv2d_wgrad(dyc, hin, 4, 4, 2, 1), Co, Cin, 4, 4)
+        G["model.%d.bias" % ci] = ops.colsum(_c2(dyc))
+        dh = ops.conv2d_dgrad(dyc, pk.conv(conv), (hin.shape[1], hin.shape[2]), 2, 1)
+    dy0 = ops.act_bwd(dh, S.y0, LRELU, 0.2)
+    G["model.0.weight"] = ops.unpack_conv_weight(ops.conv2d_wgrad(dy0, S.x4, 4, 4, 2, 1), 64, 3, 4, 4)
+    G["model.0.bias"] = ops.colsum(_c2(dy0))
+    return G
+
+
 def discriminator(dm, x):
     x = _f32c(x)
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in dm.parameters())):

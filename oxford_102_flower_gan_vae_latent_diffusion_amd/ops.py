@@ -434,6 +434,32 @@ def batchnorm_stats(x, w, b, running_mean, running_var, training, momentum=0.1, 
     return scale, shift, mean, rstd
 
 
+def batchnorm_stats_pair(x, w, b, running_mean, running_var, momentum=0.1, eps=1e-5, sync=None, world=1):
+    """Training-mode BatchNorm statistics of TWO batches stacked along dim 0 (x: (2B,H,W,C) = [first | second], e.g. the real
+    and the fake pass of the discriminator update, v2:1097-1098): each half gets its own statistics and updates the running
+    buffers in order (first, then second - what two separate passes do), and with `sync` both halves' sums travel in ONE
+    all-reduce (4C doubles) instead of one per pass. -> (scale, shift, mean, rstd) of the first half, of the second half."""
+    _chk(x, w, b, running_mean, running_var)
+    B2, H, W, C = x.shape
+    assert B2 % 2 == 0, "two stacked batches"
+    B = B2 // 2
+    halves = (x[:B], x[B:])
+    if sync is None:
+        return tuple(batchnorm_stats(h, w, b, running_mean, running_var, True, momentum, eps) for h in halves)
+    wsp, wsn = _norm_ws(B, H * W, C, x)
+    sums = torch.empty(2, 2 * C, device=x.device, dtype=torch.float64)
+    for i, h in enumerate(halves):
+        _lib.call("fl_batchnorm_sums", _p(h), None, None, None, 0, 0.0, _p(sums[i]), B, H * W, C, wsp, wsn, _stream())
+    sync(sums)
+    out = []
+    for i in range(2):
+        scale, shift, mean, rstd = (new((C,), x) for _ in range(4))
+        _lib.call("fl_batchnorm_stats_from_sums", _p(sums[i]), int(world) * B * H * W, _p(w), _p(b), float(eps), float(momentum),
+                  _p(running_mean), _p(running_var), _p(scale), _p(shift), _p(mean), _p(rstd), C, _stream())
+        out.append((scale, shift, mean, rstd))
+    return tuple(out)
+
+
 def affine_act(x, scale, shift, act=ACT_NONE, act_param=0.0, R=None, out=None):
     """y = act(x*scale + shift) (+R); scale/shift (B,C) or (C,)."""
     _chk(x, scale, shift, R, out)
@@ -492,6 +518,42 @@ def batchnorm_bwd(dy, x, scale, shift, w, mean, rstd, act=ACT_NONE, act_param=0.
     _lib.call("fl_batchnorm_bwd", _p(dy), _p(x), _p(scale), _p(shift), _p(w), _p(mean), _p(rstd), act,
               float(act_param), _p(dx), _p(dw), _p(db), _p(coef), B, H * W, C, wsp, wsn, _stream())
     return dx, dw, db
+
+
+def batchnorm_bwd_pair(dy, x, nb_a, nb_b, w, act=ACT_NONE, act_param=0.0, sync=None, world=1):
+    """Backward of batchnorm_stats_pair (+ the activation behind it): dy, x (2B,H,W,C) stacked like the forward, nb_* the halves'
+    (scale, shift, mean, rstd). -> dx (2B,H,W,C), dw, db summed over both halves (the two passes' gradients add, v2:1099-1101).
+    With `sync` the four sum vectors of both halves share ONE all-reduce."""
+    _chk(dy, x, w)
+    B2, H, W, C = x.shape
+    B = B2 // 2
+    dx = torch.empty_like(x)
+    wsp, wsn = _norm_ws(B, H * W, C, x)
+    dws, dbs = [], []
+    if sync is None:
+        for sl, nb in ((slice(0, B), nb_a), (slice(B, B2), nb_b)):
+            dw, db = new((C,), x), new((C,), x)
+            coef = new((3, C), x)
+            _lib.call("fl_batchnorm_bwd", _p(dy[sl]), _p(x[sl]), _p(nb[0]), _p(nb[1]), _p(w), _p(nb[2]), _p(nb[3]), act,
+                      float(act_param), _p(dx[sl]), _p(dw), _p(db), _p(coef), B, H * W, C, wsp, wsn, _stream())
+            dws.append(dw)
+            dbs.append(db)
+    else:
+        local = torch.empty(2, 2 * C, device=x.device, dtype=torch.float64)
+        for i, (sl, nb) in enumerate(((slice(0, B), nb_a), (slice(B, B2), nb_b))):
+            _lib.call("fl_batchnorm_sums", _p(x[sl]), _p(dy[sl]), _p(nb[0]), _p(nb[1]), act, float(act_param), _p(local[i]), B, H * W, C,
+                      wsp, wsn, _stream())
+        glob = local.clone()
+        sync(glob)
+        for i, (sl, nb) in enumerate(((slice(0, B), nb_a), (slice(B, B2), nb_b))):
+            dw, db = new((C,), x), new((C,), x)
+            coef = new((8, C), x)
+            _lib.call("fl_batchnorm_bwd_from_sums", _p(dy[sl]), _p(x[sl]), _p(nb[0]), _p(nb[1]), _p(w), _p(nb[2]), _p(nb[3]), act,
+                      float(act_param), _p(glob[i]), _p(local[i]), int(world) * B * H * W, _p(dx[sl]), _p(dw), _p(db), _p(coef), B, H * W, C,
+                      _stream())
+            dws.append(dw)
+            dbs.append(db)
+    return dx, axpby(1.0, dws[0], 1.0, dws[1]), axpby(1.0, dbs[0], 1.0, dbs[1])
 
 
 def layernorm_fwd(x, w, b, mask=None, eps=1e-5, act=ACT_NONE, act_param=0.0, save=True, R=None):

@@ -1,0 +1,78 @@
+"""The discriminator update's real and fake passes (v2:1097-1102) as ONE batch-stacked pass with per-pass BatchNorm statistics
+(engine_bwd.disc_fwd_pair / disc_bwd_pair) against the two separate passes it replaces: probabilities, summed weight gradients,
+running statistics; and the data-parallel rule - one SyncBatchNorm exchange per layer and direction for BOTH passes."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import procedural_init as pinit  # noqa: E402
+from oxford_102_flower_gan_vae_latent_diffusion_amd import engine_bwd, modules as M, ops  # noqa: E402
+
+
+def _disc(dev):
+    D = M.Discriminator64()
+    D.load_state_dict(pinit.procedural_state_dict(D.state_dict(), 43))
+    return D.to(dev).train()
+
+
+def _batches(dev, B=6):
+    g = torch.Generator().manual_seed(23)
+    return torch.rand(B, 3, 64, 64, generator=g).to(dev), (torch.rand(B, 3, 64, 64, generator=g) * 0.7 + 0.1).to(dev)
+
+
+def _two_passes(D, xa, xb, **bns):
+    pa, Sa = engine_bwd.disc_fwd(D, xa, **bns)
+    pb, Sb = engine_bwd.disc_fwd(D, xb, **bns)
+    Ga, _ = engine_bwd.disc_bwd(D, Sa, ops.bce_bwd(pa, 1.0, 0.5), need_wgrad=True, need_dx=False)
+    Gb, _ = engine_bwd.disc_bwd(D, Sb, ops.bce_bwd(pb, 0.0, 0.5), need_wgrad=True, need_dx=False)
+    return pa, pb, {k: Ga[k] + Gb[k] for k in Ga}
+
+
+def _one_pass(D, xa, xb, **bns):
+    (pa, pb), S = engine_bwd.disc_fwd_pair(D, xa, xb, **bns)
+    return pa, pb, engine_bwd.disc_bwd_pair(D, S, ops.bce_bwd(pa, 1.0, 0.5), ops.bce_bwd(pb, 0.0, 0.5))
+
+
+def _compare(ra, rb, Da, Db, tol=2e-5):
+    for x, y in zip(ra[:2], rb[:2]):
+        assert (x - y).abs().max().item() <= tol
+    for k in ra[2]:
+        ref = ra[2][k]
+        assert (rb[2][k] - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), k
+    sa, sb = Da.state_dict(), Db.state_dict()
+    for k in sa:
+        if "running" in k:
+            assert (sa[k] - sb[k]).abs().max().item() <= tol * max(1.0, sa[k].abs().max().item()), k
+        if "num_batches_tracked" in k:
+            assert int(sa[k]) == int(sb[k]) == 2
+
+
+def test_stacked_discriminator_update_equals_two_passes(dev):
+    xa, xb = _batches(dev)
+    Da, Db = _disc(dev), _disc(dev)
+    _compare(_two_passes(Da, xa, xb), _one_pass(Db, xa, xb), Da, Db)
+
+
+def test_stacked_discriminator_update_shares_one_exchange_per_layer(dev):
+    """SyncBatchNorm hook: the stacked pass exchanges 3 + 3 times (was 6 + 6) and gives the two passes' results. The hook here is a
+    one-rank 'all-reduce' that doubles the sums (two identical ranks): statistics of the global batch = this rank's batch."""
+    xa, xb = _batches(dev)
+    calls = {"two": 0, "one": 0}
+
+    def hook(tag):
+        def f(t):
+            calls[tag] += 1
+            t.mul_(2.0)
+        return f
+
+    Da, Db = _disc(dev), _disc(dev)
+    ra = _two_passes(Da, xa, xb, sync=hook("two"), world=2)
+    rb = _one_pass(Db, xa, xb, sync=hook("one"), world=2)
+    assert calls == {"two": 12, "one": 6}
+    _compare(ra, rb, Da, Db)
+    # and the global-batch rule itself: two identical ranks see the statistics of one
+    Dc = _disc(dev)
+    rc = _one_pass(Dc, xa, xb)
+    for x, y in zip(rb[:2], rc[:2]):
+        assert (x - y).abs().max().item() <= 2e-5

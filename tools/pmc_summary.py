@@ -35,8 +35,9 @@ def main():
     f, w = last_rep(rows(fdb, "FETCH_SIZE")), last_rep(rows(wdb, "WRITE_SIZE"))
     names = ["calibration: affine_act 256x32x32x128"] + ["down1 4x4s2", "res1.conv1 3x3", "res1.conv2 3x3", "down2 4x4s2", "res2.conv1 3x3",
                                                         "res2.conv2 3x3", "down3 4x4s2", "res3.conv1 3x3", "res3.conv2 3x3"]
-    fk = [r for r in f if "affine_act" in r[0] or "h2_kernel" in r[0]]
-    wk = [r for r in w if "affine_act" in r[0] or "h2_kernel" in r[0]]
+    conv = lambda n: "affine_act" in n or "h2_kernel" in n or "h2p_kernel" in n
+    fk = [r for r in f if conv(r[0])]
+    wk = [r for r in w if conv(r[0])]
     assert len(fk) == len(wk) == 10, (len(fk), len(wk))
     B = 256
     alg = [2 * 256 * 32 * 32 * 128 * 4.0]
@@ -53,13 +54,13 @@ def main():
     for n, fr, wr, a in zip(names, fk, wk, alg):
         fb, wb = 2.0 * fr[2] * 1024.0, wr[2] * 1024.0
         tot = fb + wb
-        lines.append("| %s | %s | %.1f | %.1f | %.1f | %.1f | %.2f |" % (n, short(fr[0])[:28], fb / 1e6, wb / 1e6, tot / 1e6, a / 1e6, tot / a))
+        lines.append("| %s | %s | %.1f | %.1f | %.1f | %.1f | %.2f |" % (n, short(fr[0])[:34], fb / 1e6, wb / 1e6, tot / 1e6, a / 1e6, tot / a))
         if "3x3" in n:
             out["h2_3x3"].append(tot)
         elif "4x4" in n:
             out["h2_4x4"].append(tot)
     res = {k: sum(v) / len(v) for k, v in out.items()}
-    lines += ["", "Average per launch: conv3x3_h2_kernel %.1f MB (6 launches), conv4x4s2_h2_kernel %.1f MB (3 launches) - `roofline.traffic` in the"
+    lines += ["", "Average per launch: the 3x3 convs %.1f MB (6 launches), the 4x4 / stride-2 convs %.1f MB (3 launches) - `roofline.traffic` in the"
               % (res["h2_3x3"] / 1e6, res["h2_4x4"] / 1e6), "bench line (read from profiles/%s_conv_h2_pmc.json)." % tag]
     open(os.path.join(ROOT, "profiles", "%s_conv_h2_pmc.md" % tag), "w").write("\n".join(lines) + "\n")
     json.dump(res, open(os.path.join(ROOT, "profiles", "%s_conv_h2_pmc.json" % tag), "w"))
