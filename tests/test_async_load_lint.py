@@ -35,6 +35,11 @@ def test_lint_model_flags_an_uncovered_load_and_accepts_a_covered_one():
     waw = [(None, "global_load_dword", "v4, v[2:3], off"), (None, "global_load_dwordx2", "v[4:5], v[2:3], off"),
            (None, "s_waitcnt", "vmcnt(0)"), (None, "s_endpgm", "")]
     assert t.check("k", waw) == []
+    # a wave that ends with an LDS-DMA in flight
+    dma = [(None, "global_load_lds_dwordx4", "v[8:9], off"), (None, "s_waitcnt", "vmcnt(1)"), (None, "s_endpgm", "")]
+    assert t.check("k", dma) == [(2, 0)]
+    dma[1] = (None, "s_waitcnt", "vmcnt(0)")
+    assert t.check("k", dma) == []
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join("/opt/rocm/lib/llvm/bin", "llvm-objdump")), reason="no llvm-objdump")

@@ -5,7 +5,8 @@ are written AT the asm statement).
 
 Walks the gfx950 disassembly of every kernel in a code object (all branch targets, in-flight state carried along) with the
 hardware's vmcnt model - vector-memory instructions retire in issue order, s_waitcnt vmcnt(N) leaves the N youngest in flight -
-and reports every instruction that reads or writes a VGPR a load is still in flight to. hipcc's own loads never show up (it
+and reports every instruction that reads or writes a VGPR a load is still in flight to, and every s_endpgm reached with an
+LDS-DMA (global_load_lds) still in flight (the block's LDS may belong to another block by the time it lands). hipcc's own loads never show up (it
 waits before it touches them), so a clean run means every asm load is covered by a wait on every path; the round-3 fault
 (epilogue index arithmetic scheduled into a staging register above the drain wait) is exactly one such report.
 
@@ -19,6 +20,7 @@ import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+LDS_DMA = frozenset({-1})  # marker "destination" of global_load_lds / buffer_load ... lds (no VGPR is written)
 MAX_VISITS = 12  # distinct in-flight states followed per label (loops converge after two or three)
 VMEM = re.compile(r"^(global|buffer|flat|scratch)_")
 
@@ -92,6 +94,10 @@ def check(name, ins):
                     n = int(m.group(1))
                     fl = fl[len(fl) - n:] if n else []
             elif op == "s_endpgm":
+                # a wave must not end with an LDS-DMA in flight: the block's LDS may be another block's by the time it lands
+                for at, dest in fl:
+                    if dest is LDS_DMA:
+                        reports.append((pc, at))
                 break
             else:
                 used = vregs(args)
@@ -101,8 +107,8 @@ def check(name, ins):
                     if dest & used:
                         reports.append((pc, at))
                 if VMEM.match(op):
-                    dest = frozenset()
-                    if "_load" in op and "_lds" not in op or "atomic" in op and " glc" in args:
+                    dest = LDS_DMA if ("_load" in op and "_lds" in op) or (" lds" in " " + args) else frozenset()
+                    if "_load" in op and "_lds" not in op and dest is not LDS_DMA or "atomic" in op and " glc" in args:
                         dest = frozenset(vregs(args.split(",")[0]))
                     fl.append((pc, dest))
                     fl = fl[-64:]
@@ -139,7 +145,7 @@ def main():
                         demangled = subprocess.run(["c++filt", name], stdout=subprocess.PIPE, text=True).stdout.strip() or name
                     except OSError:
                         demangled = name
-                    print("%s\n    +%d  %s %s\n    touches a register of the load still in flight from +%d  %s %s" %
+                    print("%s\n    +%d  %s %s\n    touches a register of (or ends under) the load still in flight from +%d  %s %s" %
                           (demangled, pc, ins[pc][1], ins[pc][2], at, ins[at][1], ins[at][2]))
     print("%d kernels checked, %d reports" % (total, bad))
     return 1 if bad else 0
