@@ -22,7 +22,7 @@ def test_lint_model_flags_an_uncovered_load_and_accepts_a_covered_one():
     t = _tool()
     covered = [(None, "global_load_dwordx4", "v[4:7], v[2:3], off"), (None, "global_load_lds_dwordx4", "v[8:9], off"),
                (None, "v_add_u32_e32", "v1, v2, v3"), (None, "s_waitcnt", "vmcnt(1)"), (None, "v_mov_b32_e32", "v10, v5"),
-               (None, "s_endpgm", "")]
+               (None, "s_waitcnt", "vmcnt(0)"), (None, "s_endpgm", "")]
     assert t.check("k", covered) == []
     late = list(covered)
     late[3] = (None, "s_waitcnt", "vmcnt(2)")
