@@ -388,6 +388,17 @@ def vgg_features(vgg, x, save):
     return h, tape
 
 
+def vgg_features_pair(vgg, x, y):
+    """features of x (with the tape its input gradient needs) and of y (none: the target of the perceptual loss, v2:976-980) from
+    ONE batch-stacked pass over [x | y] - the VGG is frozen and has no batch statistics, so stacking changes nothing but the
+    launch count and the tile fill (and, in f16x2 math, the shared power-of-two operand scale: the larger of the two ranges).
+    -> fx, fy, tape (views of the first half)."""
+    B = x.shape[0]
+    f, tape2 = vgg_features(vgg, torch.cat((x, y), 0), True)
+    tape = [(kind, layer, hin[:B], hout[:B]) for kind, layer, hin, hout in tape2]
+    return f[:B], f[B:], tape
+
+
 def vgg_features_bwd(vgg, tape, dfeat):
     """input gradient only (the VGG is frozen, v2:966-967)."""
     pk = vgg._pk

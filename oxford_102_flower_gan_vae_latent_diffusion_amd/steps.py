@@ -16,6 +16,8 @@ from . import engine, engine_bwd, ops
 
 # the discriminator update's real and fake passes as one batch-stacked pass (engine_bwd.disc_fwd_pair); FL_PAIRED_D=0: two passes
 PAIRED_D_PASSES = os.environ.get("FL_PAIRED_D", "1") != "0"
+# the perceptual loss's two VGG passes (reconstruction, target) as one batch-stacked pass; FL_STACKED_VGG=0: two passes
+STACKED_VGG = os.environ.get("FL_STACKED_VGG", "1") != "0"
 
 
 class FlatParams:
@@ -624,8 +626,11 @@ class VAEGANTrainer:
         recon, S_dec = engine_bwd.decoder_fwd(ae.decoder, z)
         # ---- losses (v2:1090-1094) ----
         recon_loss, rn = ops.euclid_loss_fwd(recon, data)
-        fx, tape = engine_bwd.vgg_features(vgg, recon, True)
-        fy, _ = engine_bwd.vgg_features(vgg, data, False)
+        if STACKED_VGG:
+            fx, fy, tape = engine_bwd.vgg_features_pair(vgg, recon, data)
+        else:
+            fx, tape = engine_bwd.vgg_features(vgg, recon, True)
+            fy, _ = engine_bwd.vgg_features(vgg, data, False)
         percep, pn = ops.euclid_loss_fwd(fx, fy)
         zero = torch.zeros(1, dtype=torch.float32, device=self.dev)
         W = self.world

@@ -76,3 +76,22 @@ def test_stacked_discriminator_update_shares_one_exchange_per_layer(dev):
     rc = _one_pass(Dc, xa, xb)
     for x, y in zip(rb[:2], rc[:2]):
         assert (x - y).abs().max().item() <= 2e-5
+
+
+def test_stacked_vgg_passes_equal_two_passes(dev):
+    """The perceptual loss's VGG16[:16] passes over the reconstruction (with the tape of its input gradient) and over the target as
+    one stacked pass: same features and the same input gradient as two passes, to the f16x2 error class (the stacked pass scales
+    both halves by the larger of the two input ranges: 3e-6 of the feature maximum per conv)."""
+    xa, xb = _batches(dev, B=8)
+    vgg = M.VGGPerceptualLoss(dev, state_dict=pinit.procedural_state_dict(pinit.vgg16_features16_shapes(""), 7))
+    fx0, tape0 = engine_bwd.vgg_features(vgg, xa, True)
+    fy0, _ = engine_bwd.vgg_features(vgg, xb, False)
+    fx1, fy1, tape1 = engine_bwd.vgg_features_pair(vgg, xa, xb)
+    fmax = max(fx0.abs().max().item(), fy0.abs().max().item())
+    assert (fx1 - fx0).abs().max().item() <= 3e-5 * fmax and (fy1 - fy0).abs().max().item() <= 3e-5 * fmax
+    g = torch.Generator().manual_seed(5)
+    dfx = torch.randn(fx0.shape, generator=g).to(dev)
+    dx0 = engine_bwd.vgg_features_bwd(vgg, tape0, dfx)
+    dx1 = engine_bwd.vgg_features_bwd(vgg, tape1, dfx)
+    assert dx1.shape == xa.shape
+    assert (dx1 - dx0).abs().max().item() <= 1e-4 * dx0.abs().max().item()
