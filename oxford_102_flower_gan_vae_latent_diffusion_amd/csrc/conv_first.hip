@@ -24,8 +24,11 @@ typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 // weights are scaled by the power of two that puts their largest magnitude in [2^14, 2^15) (found by the wave itself) and
 // split once per wave; the taps are scaled by 2^6 (|x| < 1023: images, VGG-normalised images; larger inputs give NaN, loudly)
 // and split per pixel group. k = 4 tap + channel: group g of 16 k = taps 4g..4g+3 (lane half lh: taps 4g+2lh, 4g+2lh+1).
+#ifndef FL_STEM_OCC
+#define FL_STEM_OCC 2  // waves per SIMD the f16x2 variant is compiled for (A/B knob, tools/build_variant_lib.sh)
+#endif
 template <bool STATS, int ACT, bool H2>
-__global__ __launch_bounds__(256, H2 ? 2 : 3) void conv3x3_c4_o64_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, H2 ? FL_STEM_OCC : 3) void conv3x3_c4_o64_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              float* __restrict__ partial, int H, int W, float act_param) {
   const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
