@@ -668,6 +668,43 @@ def test_f16x2_conv_fused_preop(dev, B, Cin, Cout, H, k, s, p):
     close(y, y2.cpu(), tol=3e-6)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,k,s,p,pre", [(16, 512, 512, 8, 3, 1, 1, True), (16, 256, 256, 16, 3, 1, 1, True), (8, 128, 128, 32, 3, 1, 1, False),
+                                                    (8, 32, 128, 32, 3, 1, 1, True), (8, 64, 128, 64, 4, 2, 1, True), (16, 256, 512, 16, 4, 2, 1, False)])
+def test_f16x2_convs_are_bit_stable_next_to_a_streaming_queue(dev, B, Cin, Cout, H, k, s, p, pre):
+    """The conv kernels' halo loads are asynchronous inline-asm loads waited for by hand-counted s_waitcnt: their results must not depend
+    on WHEN a load lands. Forty launches of each kernel family on one stream while a second stream saturates the memory system (268 MB
+    streaming passes) must reproduce, bit for bit, the output of a launch on an idle device. (Round 3's fault - DESIGN 7c - was a halo
+    load landing late into a register the compiler had reused: it needed exactly this, a loaded memory system, to show.)"""
+    x, w, b = _h2_setup(B, Cin, Cout, H, k, s, p, seed=60)
+    xh, wp, bd = nhwc(x).to(dev), ops.pack_conv_weight(w.to(dev)), b.to(dev)
+    wh2, geom = ops.pack_weight_f16x2(wp), tuple(wp.shape)
+    amax = torch.full((1,), float(x.abs().max()) * 4.0, device=dev)
+    kw = dict(x_amax=amax)
+    if pre:
+        kw["pre"] = (rnd(B, Cin, seed=61).abs().to(dev) + 0.5, rnd(B, Cin, seed=62, scale=0.5).to(dev))
+    ref = ops.conv2d_fwd_f16x2(xh, wh2, geom, bd, s, p, **kw).clone()
+    torch.cuda.synchronize()
+    big, out = torch.empty(256, 32, 32, 256, device=dev), torch.empty(256, 32, 32, 256, device=dev)
+    ops.philox_fill(big, seed=3, mode=0)
+    sc, sh = torch.ones(256, 256, device=dev), torch.zeros(256, 256, device=dev)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    ys = []
+    old_slot = ops.set_workspace_slot(1)  # (these launches take no scratch; the second queue gets its own slot all the same)
+    try:
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                ys.append(ops.conv2d_fwd_f16x2(xh, wh2, geom, bd, s, p, **kw))
+    finally:
+        ops.set_workspace_slot(old_slot)
+    for _ in range(24):  # ~0.1 ms each: the hog outlasts the convs on the other queue
+        ops.affine_act(big, sc, sh, act=ops.ACT_SWISH, out=out)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    for i, y in enumerate(ys):
+        assert torch.equal(y, ref), "launch %d differs from the idle-device result" % i
+
+
 def test_f16x2_range_is_loud_not_silent(dev):
     """|x| * 2^e beyond fp16's range must poison the output (inf - inf = NaN), never pass silently; a correct amax bound
     makes the same data exact again."""
