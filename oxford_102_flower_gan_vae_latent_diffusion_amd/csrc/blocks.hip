@@ -143,6 +143,68 @@ __global__ void res_tail_out_kernel(const float* __restrict__ y, const float* __
   }
 }
 
+// The streaming form of res_tail_out_kernel for the case the encoder runs it in (gate precomputed by sa_att_kernel, residual given):
+// a lane group walks RUN CONSECUTIVE pixels of one image, so the five per-(image, channel) coefficient vectors are loaded once per
+// run instead of once per pixel (they were 5 of the 7 loads of every pixel: cache hits, but each a full pass through the texture
+// path), and the run's loads go out UNR pixels at a time before the first of them is used. Same arithmetic as res_tail_out_kernel
+// (the two agree to 1-3 ulp: hipcc contracts the multiply-adds of the two bodies differently; tools/res_tail_equal.py).
+// Stage 1 / 2 / 3 of the encoder at batch 256: gate + tail 97.6 -> 85.6 us at stage 1, encoder graph 2.236 -> 2.205 ms.
+template <int LPP, int RUN>
+__global__ __launch_bounds__(256) void res_tail_stream_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const float* __restrict__ s,
+                                                              const float* __restrict__ xres, const float* __restrict__ xs,
+                                                              const float* __restrict__ xh, float* __restrict__ out,
+                                                              const float* __restrict__ att_in, long long npix, int HW, int C,
+                                                              int final_swish, int s_per_image) {
+  constexpr int PPW = 64 / LPP, UNR = 4;
+  static_assert(RUN % UNR == 0, "run length");
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int gl = lane % LPP, gp = lane / LPP;
+  const int C4 = C >> 2;
+  const long long pix0 = (((long long)blockIdx.x * (blockDim.x >> 6) + wid) * PPW + gp) * RUN;  // HW % RUN == 0: one image per run
+  if (pix0 >= npix) return;
+  const int b = (int)(pix0 / HW);
+  for (int c4 = gl; c4 < C4; c4 += LPP) {
+    const long long bc = (long long)b * C + c4 * 4;
+    const float4 sc = scale ? ld4(scale + bc) : make_float4(1.f, 1.f, 1.f, 1.f), sh = scale ? ld4(shift + bc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 ss = s ? ld4(s + (s_per_image ? (long long)b * C : 0) + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 a = xs ? ld4(xs + bc) : make_float4(1.f, 1.f, 1.f, 1.f), d = xs ? ld4(xh + bc) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int i0 = 0; i0 < RUN; i0 += UNR) {
+      float4 v[UNR], r[UNR];
+      float att[UNR];
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+        const long long off = (pix0 + i0 + i) * C + c4 * 4;
+        v[i] = ld4(y + off);
+        r[i] = ld4(xres + off);
+        att[i] = att_in[pix0 + i0 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < UNR; ++i) {
+        float4 u = v[i];
+        if (scale) { u.x = u.x * sc.x + sh.x; u.y = u.y * sc.y + sh.y; u.z = u.z * sc.z + sh.z; u.w = u.w * sc.w + sh.w; }
+        if (s) { u.x *= ss.x; u.y *= ss.y; u.z *= ss.z; u.w *= ss.w; }
+        u.x *= att[i]; u.y *= att[i]; u.z *= att[i]; u.w *= att[i];
+        float4 q = r[i];
+        if (xs) {
+          q.x = fl::swish_fast(q.x * a.x + d.x); q.y = fl::swish_fast(q.y * a.y + d.y);
+          q.z = fl::swish_fast(q.z * a.z + d.z); q.w = fl::swish_fast(q.w * a.w + d.w);
+        }
+        u.x += q.x; u.y += q.y; u.z += q.z; u.w += q.w;
+        if (final_swish) {
+          if (xs) {
+            u.x = fl::swish_fast(u.x); u.y = fl::swish_fast(u.y); u.z = fl::swish_fast(u.z); u.w = fl::swish_fast(u.w);
+          } else {
+            u.x = fl::swish_acc(u.x); u.y = fl::swish_acc(u.y); u.z = fl::swish_acc(u.z); u.w = fl::swish_acc(u.w);
+          }
+        }
+        st4(out + (pix0 + i0 + i) * C + c4 * 4, u);
+      }
+    }
+  }
+}
+
 // att[b, p] = sigmoid(conv7x7([mean | max] map, saw)) (v2:76-79): one thread per pixel on the L2-resident 2-plane map.
 // Inside res_tail_out_kernel the 98-tap stencil (lanes splitting the taps, a shuffle tree, the sigmoid) sat in front of every
 // pixel's channel stream and cost 59 of its 135 us at the 32x32x128 stage (tools/res_tail_probe.py).
@@ -228,6 +290,17 @@ int fl_res_tail_out_pre(const float* y, const float* scale, const float* shift, 
     att_in = att_out;
     att_out = nullptr;
     map = nullptr;
+  }
+  // the streaming form: gate precomputed, residual given, whole runs of 8 pixels inside an image (FL_TAIL_STREAM=0: the general kernel)
+  static const bool stream_ok = !(getenv("FL_TAIL_STREAM") && getenv("FL_TAIL_STREAM")[0] == '0');
+  if (stream_ok && att_in && xres && !map && !att_out && (H * W) % 8 == 0 && C4 >= 16) {
+    const long long runs = npix / 8;
+#define LAUNCH_STREAM(L) hipLaunchKernelGGL((res_tail_stream_kernel<L, 8>), dim3((unsigned)((runs + 4 * (64 / L) - 1) / (4 * (64 / L)))), dim3(256), 0, st, y, scale, shift, s, xres, xres_scale, xres_shift, out, att_in, npix, H * W, C, final_swish, s_per_image)
+    if (C4 >= 64) LAUNCH_STREAM(64);
+    else if (C4 >= 32) LAUNCH_STREAM(32);
+    else LAUNCH_STREAM(16);
+#undef LAUNCH_STREAM
+    return fl::check_launch("res_tail_stream_kernel");
   }
 #define LAUNCH_OUT(L) hipLaunchKernelGGL(res_tail_out_kernel<L>, dim3(tail_blocks(npix, 64 / L)), dim3(256), 0, st, y, scale, shift, s, map, saw, xres, xres_scale, xres_shift, out, att_out, B, H, W, C, final_swish, s_per_image, att_in)
   if (C4 >= 64) LAUNCH_OUT(64);

@@ -342,6 +342,31 @@ def test_res_tail(dev, B, C, H, W):
     close(nchw(out2), y.double() * s.double().view(B, C, 1, 1), tol=1e-6)
 
 
+@pytest.mark.parametrize("B,C,H", [(3, 128, 8), (2, 256, 16), (2, 512, 8), (2, 128, 6), (2, 32, 8)])
+def test_res_tail_with_fused_residual_preop(dev, B, C, H):
+    """The inference form: the residual enters as swish(x * a[b,c] + d[b,c]) (its LayerNorm2d-apply fused in). Whole 8-pixel runs and
+    C >= 64 take res_tail_stream_kernel (coefficients loaded once per run), the rest (6x6 maps, C = 32) the general kernel: both
+    against fp64 (fast Swish: 3e-5)."""
+    y, xres = rnd(B, C, H, H, seed=11), rnd(B, C, H, H, seed=12)
+    scale, shift, s = 1 + 0.1 * rnd(B, C, seed=13), 0.1 * rnd(B, C, seed=14), torch.sigmoid(rnd(C, seed=15))
+    a, d = rnd(B, C, seed=16).abs() + 0.5, rnd(B, C, seed=17, scale=0.3)
+    saw = rnd(1, 2, 7, 7, seed=18, scale=0.2)
+    v = lambda t: t.double().view(B, C, 1, 1)
+    u = (y.double() * v(scale) + v(shift)) * s.double().view(1, C, 1, 1)
+    m = torch.cat([u.mean(1, keepdim=True), u.max(1, keepdim=True)[0]], 1)
+    att = torch.sigmoid(F.conv2d(m, saw.double(), padding=3))
+    r = xres.double() * v(a) + v(d)
+    r = r * torch.sigmoid(r)
+    for fs in (True, False):
+        ref = u * att + r
+        ref = ref * torch.sigmoid(ref) if fs else ref
+        yd = nhwc(y).to(dev)
+        mp = ops.res_tail_map(yd, scale.to(dev), shift.to(dev), s.to(dev))
+        out = ops.res_tail_out(yd, scale.to(dev), shift.to(dev), s.to(dev), mp, saw.to(dev).contiguous(), nhwc(xres).to(dev),
+                               final_swish=fs, xres_pre=(a.to(dev), d.to(dev)))
+        close(nchw(out), ref, tol=3e-5)
+
+
 def test_elementwise_and_layout(dev):
     x = rnd(3, 3, 8, 8, seed=1)
     y = ops.nchw_to_nhwc(x.to(dev), 4)

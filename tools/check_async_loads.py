@@ -128,7 +128,7 @@ def check(name, ins):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--kernels"]
     here = os.path.dirname(os.path.abspath(__file__))
     lib = args[0] if args else os.path.join(here, "..", "oxford_102_flower_gan_vae_latent_diffusion_amd", "libflowers_hip.so")
     pat = re.compile(sys.argv[sys.argv.index("--kernels") + 1]) if "--kernels" in sys.argv else None
