@@ -13,6 +13,9 @@ from . import engine, ops
 PERSISTENT = os.environ.get("FL_PERSISTENT", "1") != "0"
 
 
+STEPS_PER_GRAPH = int(os.environ.get("FL_SAMPLER_STEPS_PER_GRAPH", "10"))
+
+
 class GraphSampler:
     """persistent=True (default): one reverse step is ONE launch of the persistent phase program (program.SamplerProgram:
     denoiser with the x-independent paths hoisted and the eval-mode linear chains folded, the update, inline Philox
@@ -64,7 +67,20 @@ class GraphSampler:
             with torch.cuda.graph(g):
                 self._step()
             self.graph = g
-            for _ in range(n_steps - done):
+            left = n_steps - done
+            # every graph launch costs ~9 us of idle device between its last kernel and the next launch's first (profiles/
+            # r03_step_timeline.txt): a reverse step is 0.17 ms, so long runs replay STEPS_PER_GRAPH steps per launch (the step's
+            # timestep, counters and draws are device-resident: the captured step is the same launch every time)
+            if left >= 2 * STEPS_PER_GRAPH:
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, pool=g.pool()):
+                    for _ in range(STEPS_PER_GRAPH):
+                        self._step()
+                self.graph_k = gk
+                for _ in range(left // STEPS_PER_GRAPH):
+                    gk.replay()
+                left -= (left // STEPS_PER_GRAPH) * STEPS_PER_GRAPH
+            for _ in range(left):
                 g.replay()
         else:
             for _ in range(n_steps - done):

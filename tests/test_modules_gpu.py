@@ -198,6 +198,14 @@ def test_sampler_graph_equals_eager_and_oracle(dev, unet):
     b = GraphSampler(d, (B, 256), dev, c, use_graph=False).run(x_T, n_steps=12, t_start=11).clone()
     assert torch.equal(a, b), "graph replay must be bit-identical to eager"
     assert torch.isfinite(a).all()
+    # long runs replay several reverse steps per graph launch (sampler.STEPS_PER_GRAPH) plus single-step launches for the rest:
+    # 1 eager + 2 x 10 + 6 x 1 here, in both sampler modes, down to t = 0 (the step that adds no noise)
+    for persistent in (True, False):
+        d.rng.manual_seed(7)
+        a = GraphSampler(d, (B, 256), dev, c, use_graph=True, persistent=persistent).run(x_T, n_steps=27, t_start=26).clone()
+        d.rng.manual_seed(7)
+        b = GraphSampler(d, (B, 256), dev, c, use_graph=False, persistent=persistent).run(x_T, n_steps=27, t_start=26).clone()
+        assert torch.equal(a, b), "multi-step graph replay must be bit-identical to eager (persistent=%s)" % persistent
     # full-length API smoke (short schedule): sample() and its alias
     d2 = M.ConditionalDenoiseDiffusion(unet, n_steps=8, device=dev)
     s = d2.sample((B, 256), dev, c)
