@@ -656,7 +656,7 @@ class VAEGANTrainer:
             cen = zero
         # ---- discriminator update (v2:1097-1102) ----
         bns = dict(sync=self.bn_sync, world=self.world)
-        if PAIRED_D_PASSES:
+        if PAIRED_D_PASSES and D.training:  # (an eval-mode discriminator normalises with its running statistics: two plain passes)
             # the real and the fake pass as one batch-stacked pass with per-pass BatchNorm statistics: half the launches, weight-
             # gradient GEMMs over both batches, and one SyncBatchNorm exchange per layer and direction for both (12 per step, was 18)
             (p_real, p_fake), S_d = engine_bwd.disc_fwd_pair(D, data, recon, **bns)  # recon_x.detach(): no gradient reaches the AE
