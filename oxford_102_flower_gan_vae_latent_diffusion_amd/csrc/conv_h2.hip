@@ -214,6 +214,7 @@ struct H2Geom {
   static constexpr int BM = BM_, BN = 128;
   static constexpr int R = BM / W, RI = R < W ? R : W, NI = R / RI, HR = RI + 2, HC = W + 2;
   static constexpr int PXB = 48;  // bytes per staged pixel and plane: 16 halfs + 8 pad (odd multiple of 16 B: conflict-free b128)
+  static constexpr int PAD_OFF = 32;  // the idle staging lanes write the pad of pixel 0
   // row pitch: the 32 lanes of a fragment read are 32 consecutive output pixels; for W < 32 they span several rows and the
   // jump to the next row must look like "the next W pixels" to the 64 banks: RPB == W * PXB (mod 256 B)
   static constexpr int RPB = W == 32 ? HC * PXB : (W == 16 ? 1024 : 640);
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2_kernel(const H2Args g) 
     goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
     // threads past the last item write into the 16 pad bytes of pixel 0 (branch-free staging: the conversion is interleaved
     // with MFMAs, which needs one basic block)
-    sdst[j] = (i < ITEMS) ? (nl * HR + hy) * RPB + hx * PXB + c4 * 8 : 32;
+    sdst[j] = (i < ITEMS) ? (nl * HR + hy) * RPB + hx * PXB + c4 * 8 : G::PAD_OFF;
     ssoff[j] = (nl < NI ? nl : 0) * Cin + c4 * 4;
     vmask |= (ok ? 1u : 0u) << j;
   }
@@ -573,10 +574,19 @@ template <int W, int BM_>
 struct H2PGeom {
   static constexpr int BM = BM_, BN = 128;
   static constexpr int R = BM / W, RI = R < W ? R : W, NI = R / RI, HR = RI + 2, HC = W + 2;
-  static constexpr int PXB = 48;
-  // W = 8: the conflict-free pitch (640) does not leave room for the 48 KB ring next to 16 KB of pre-op coefficients (Cin = 512):
-  // 480 costs a 2-way conflict on two of a read's sixteen 16-byte slots
-  static constexpr int RPB = W == 32 ? HC * PXB : (W == 16 ? 1024 : 480);
+#ifndef FL_H2P_PXB
+#define FL_H2P_PXB 32  // 48: the 32x32x16 kernel's pitches (A/B build, tools/build_variant_lib.sh)
+#endif
+  // Pixel pitch 32 B = the 16 halfs, no pad. The A fragment of the 16x16x32 MFMA is read by lane (l16, kg) at pixel l16 + 16 B * (kg & 1),
+  // and a ds_read_b128 is served in the 16-lane groups {0-3, 12-15, 20-27}, ... : with two 16-byte slots per pixel the eight kg-even
+  // lanes of a group land on the even slots and the eight kg-odd lanes on the odd ones - conflict-free. (The 32x32x16 kernel's 48-byte
+  // pitch, conflict-free for ITS lane map, cost this one a 2-way conflict on every A read, 3-way on the 8-wide maps, and 2-way on the
+  // staging writes: SQ_LDS_BANK_CONFLICT was 33 % / 47 % of SQ_LDS_IDX_ACTIVE, profiles/r03_conv_sq_pmc.md.) A group spans two image rows
+  // only on the 8-wide maps: there the row pitch is a multiple of 256 B. Every row keeps >= 16 B of pad (the idle staging lanes' target).
+  static constexpr int PXB = FL_H2P_PXB;
+  static constexpr int RPB = PXB == 32 ? (W == 32 ? HC * PXB + 32 : (W == 16 ? HC * PXB + 64 : 512))
+                                       : (W == 32 ? HC * PXB : (W == 16 ? 1024 : 480));
+  static constexpr int PAD_OFF = PXB == 32 ? HC * PXB : 32;  // 8 bytes nobody reads, in both planes
   static constexpr int PLANE_B = NI * HR * RPB, ABUF_B = 2 * PLANE_B;
   static constexpr int NS = 3, SLOT_B = 16384, BOFF = 2 * ABUF_B;
   static constexpr int LDS_B = BOFF + NS * SLOT_B;
@@ -637,7 +647,7 @@ __global__ __launch_bounds__(2 * BM_, 2) void conv3x3_h2p_kernel(const H2Args g)
     const int iy = oy0 - 1 + hy, ix = hx - 1;
     const bool ok = (i < ITEMS) && ((unsigned)iy < (unsigned)W) && ((unsigned)ix < (unsigned)W);
     goff[j] = ok ? (((img0 + nl) * W + iy) * W + ix) * Cin + c4 * 4 : 0;
-    sdst[j] = (i < ITEMS) ? (nl * HR + hy) * RPB + hx * PXB + c4 * 8 : 32;
+    sdst[j] = (i < ITEMS) ? (nl * HR + hy) * RPB + hx * PXB + c4 * 8 : G::PAD_OFF;
     ssoff[j] = (nl < NI ? nl : 0) * Cin + c4 * 4;
     vmask |= (ok ? 1u : 0u) << j;
   }
