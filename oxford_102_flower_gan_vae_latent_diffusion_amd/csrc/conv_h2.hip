@@ -1261,7 +1261,19 @@ __global__ __launch_bounds__(512, 2) void conv4x4s2_h2_kernel(const H2Args g) {
 // (8 steps per loop period is not a multiple of 3).
 template <int WO>
 struct H2PGeom4 : H2Geom4<WO> {
-  static constexpr int NS = 3, SLOT_B = 16384, BOFF = 2 * H2Geom4<WO>::ABUF_B;
+#ifndef FL_H2P4_PITCH
+#define FL_H2P4_PITCH 1  // 0: A/B build with H2Geom4's planes on the 64-wide input stage too
+#endif
+  // The planes are H2Geom4's. For the 16x16x32 lane map the 64-wide stage's parity plane (9504 B, not a multiple of 256) puts the kg-odd
+  // lanes of a ds_read_b128 group on the kg-even lanes' slots: 2-way on every A read (SQ_LDS_BANK_CONFLICT 34 % of down1's LDS cycles,
+  // profiles/r03_conv_sq_pmc.md). Row pitch 544 with the plane padded by 192 B clears the reads (brute force of the bank rule): down1
+  // 0.2366 -> 0.2332 ms with the pre-op, 0.2178 -> 0.2165 plain (profiles/r03_experiments.md). The 32- and 16-wide stages read
+  // conflict-free as they are (their conflicts are staging writes).
+  using B4 = H2Geom4<WO>;
+  static constexpr int RPB = (FL_H2P4_PITCH && WO == 32) ? 544 : B4::RPB;
+  static constexpr int PAR_B = B4::NI * B4::HR * RPB + ((FL_H2P4_PITCH && WO == 32) ? 192 : 0);
+  static constexpr int PLANE_B = 2 * PAR_B, ABUF_B = 2 * PLANE_B;
+  static constexpr int NS = 3, SLOT_B = 16384, BOFF = 2 * ABUF_B;
   static constexpr int LDS_B = BOFF + NS * SLOT_B;
 };
 
